@@ -1,0 +1,141 @@
+"""Encoder geometries for the SSL embedding-extraction path.
+
+The reference never spells these numbers out: it calls
+``AutoModel.from_pretrained(--ssl_type)`` (preprocess_speech.py:111-114,
+preprocess_whisper.py:119-122) and the hub ``config.json`` supplies them.
+SURVEY.md section 8a cross-checks the values below against parameter counts and
+the ``feat1_dim`` entries of the reference's configs/*.json.
+
+A geometry is a plain dataclass so that the CPU oracle (oracle/) can consume it
+by attribute access without importing this package.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import Tuple
+
+FAMILY_WAVLM = "wavlm"
+FAMILY_WAV2VEC2 = "wav2vec2"
+FAMILY_HUBERT = "hubert"
+FAMILY_WHISPER = "whisper"
+
+SPEECH_FAMILIES = (FAMILY_WAVLM, FAMILY_WAV2VEC2, FAMILY_HUBERT)
+
+
+@dataclass(frozen=True)
+class EncoderGeometry:
+    family: str
+    num_layers: int
+    hidden: int
+    heads: int
+    ffn: int
+    # wav2vec2-style convolutional waveform encoder (all three speech families)
+    conv_dim: Tuple[int, ...] = (512,) * 7
+    conv_kernel: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    conv_bias: bool = False
+    feat_proj_layer_norm: bool = True      # HuBERT makes this optional
+    pos_conv_kernel: int = 128
+    pos_conv_groups: int = 16
+    # WavLM gated relative position bias
+    num_buckets: int = 320
+    max_bucket_distance: int = 800
+    layer_norm_eps: float = 1e-5
+    # Whisper encoder
+    n_mels: int = 128
+    max_source_positions: int = 1500
+    name: str = ""
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def num_hidden_states(self) -> int:
+        return self.num_layers + 1
+
+    def frames_for(self, num_samples: int) -> int:
+        """Integer frame count of the conv stack: floor((L-k)/s)+1 per layer
+        (HF modeling_wavlm.py:633-652).  Bit-exact gate of SURVEY 8a row a8."""
+        n = int(num_samples)
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            n = (n - k) // s + 1
+        return n
+
+    def frame_chain(self, num_samples: int):
+        out = []
+        n = int(num_samples)
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            n = (n - k) // s + 1
+            out.append(n)
+        return out
+
+
+WAVLM_LARGE = EncoderGeometry(
+    family=FAMILY_WAVLM, num_layers=24, hidden=1024, heads=16, ffn=4096,
+    conv_bias=False, name="microsoft/wavlm-large")
+
+XLSR_2B = EncoderGeometry(
+    family=FAMILY_WAV2VEC2, num_layers=48, hidden=1920, heads=16, ffn=7680,
+    conv_bias=True, name="facebook/wav2vec2-xls-r-2b")
+
+HUBERT_XLARGE = EncoderGeometry(
+    family=FAMILY_HUBERT, num_layers=48, hidden=1280, heads=16, ffn=5120,
+    conv_bias=True, feat_proj_layer_norm=True,
+    name="facebook/hubert-xlarge-ls960-ft")
+
+WHISPER_LARGE_V3 = EncoderGeometry(
+    family=FAMILY_WHISPER, num_layers=32, hidden=1280, heads=20, ffn=5120,
+    n_mels=128, max_source_positions=1500, name="openai/whisper-large-v3")
+
+_REGISTRY = {
+    "microsoft/wavlm-large": WAVLM_LARGE,
+    "wavlm-large": WAVLM_LARGE,                       # the reference's argparse default
+    "facebook/wav2vec2-xls-r-2b": XLSR_2B,
+    "facebook/hubert-xlarge-ls960-ft": HUBERT_XLARGE,
+    "facebook/hubert-xlarge-ll60k": HUBERT_XLARGE,
+    "openai/whisper-large-v3": WHISPER_LARGE_V3,
+}
+
+
+def tiny_geometry(family: str, *, hidden: int = 128, heads: int = 2, layers: int = 2,
+                  ffn: int = 256, conv_dim: int = 64, pos_groups: int = 2) -> EncoderGeometry:
+    """Small geometries with the real kernel/stride tuples; used by the parity
+    fixtures under tests/golden.  ``hidden // heads`` selects
+    the head-dim code path (64 WavLM/Whisper, 80 HuBERT-XL, 120 XLS-R-2B) and
+    ``hidden // pos_groups`` the pos-conv group width (64 / 80 / 120 in the real models)."""
+    if family == FAMILY_WHISPER:
+        return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads,
+                               ffn=ffn, n_mels=128, max_source_positions=1500,
+                               name=f"tiny-{family}-d{hidden}h{heads}")
+    return EncoderGeometry(
+        family=family, num_layers=layers, hidden=hidden, heads=heads, ffn=ffn,
+        conv_dim=(conv_dim,) * 7, conv_bias=(family != FAMILY_WAVLM),
+        pos_conv_groups=pos_groups,
+        name=f"tiny-{family}-d{hidden}h{heads}")
+
+
+def geometry_for(ssl_type: str) -> EncoderGeometry:
+    """Map ``--ssl_type`` to a geometry.  Unknown names raise ``OSError`` because
+    that is what ``from_pretrained`` raises in the reference and what its driver
+    catches (preprocess_speech.py:115-117)."""
+    key = ssl_type.strip()
+    if key in _REGISTRY:
+        return _REGISTRY[key]
+    low = key.lower()
+    for name, geo in _REGISTRY.items():
+        if low == name.lower() or low == name.split("/")[-1].lower():
+            return geo
+    raise OSError(f"No geometry registered for ssl_type '{ssl_type}'")
+
+
+def with_layers(geo: EncoderGeometry, layers: int) -> EncoderGeometry:
+    return replace(geo, num_layers=layers)
+
+
+# The four fixture geometries under tests/golden (head dims 64 / 120 / 80 / 64 and
+# pos-conv group widths 64 / 120 / 80, i.e. every code path of the real models).
+TINY_WAVLM = tiny_geometry(FAMILY_WAVLM, hidden=128, heads=2, ffn=256, pos_groups=2)
+TINY_WAV2VEC2 = tiny_geometry(FAMILY_WAV2VEC2, hidden=960, heads=8, ffn=512, pos_groups=8)
+TINY_HUBERT = tiny_geometry(FAMILY_HUBERT, hidden=320, heads=4, ffn=384, pos_groups=4)
+TINY_WHISPER = tiny_geometry(FAMILY_WHISPER, hidden=128, heads=2, ffn=256)

@@ -1,0 +1,168 @@
+"""Frozen-encoder weights: HuggingFace state-dict names in, plain fp32 tensors out.
+
+The reference obtains weights with ``AutoModel.from_pretrained(--ssl_type)``
+(preprocess_speech.py:112, preprocess_whisper.py:120).  There is no network in
+the build or benchmark environment, so two sources are supported:
+
+* ``load_checkpoint(path)``   -- a local ``*.safetensors`` / ``pytorch_model.bin``
+  (file or HF snapshot directory) using the hub's parameter names, so a real
+  checkpoint drops in unchanged;
+* ``synthetic_state_dict(geo, seed)`` -- seeded random tensors of the same names
+  and shapes (benchmarks, parity tests).  Scales are chosen so that every code
+  path carries signal: non-unit LayerNorm affine, peaky attention, non-trivial
+  relative-position bias and gate.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict
+
+import torch
+
+from .config import EncoderGeometry, FAMILY_WAVLM, FAMILY_WHISPER
+
+StateDict = Dict[str, torch.Tensor]
+
+
+class _Rng:
+    def __init__(self, seed: int):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(int(seed))
+
+    def normal(self, *shape, std=1.0, mean=0.0):
+        return torch.randn(*shape, generator=self.g, dtype=torch.float32) * std + mean
+
+
+def _linear(sd, r, name, out_f, in_f, gain=0.7, bias=True):
+    sd[name + ".weight"] = r.normal(out_f, in_f, std=gain / math.sqrt(in_f))
+    if bias:
+        sd[name + ".bias"] = r.normal(out_f, std=0.05)
+
+
+def _layer_norm(sd, r, name, dim):
+    sd[name + ".weight"] = r.normal(dim, std=0.1, mean=1.0)
+    sd[name + ".bias"] = r.normal(dim, std=0.1)
+
+
+def whisper_sinusoids(length: int, channels: int) -> torch.Tensor:
+    """Whisper's frozen position table at init (HF modeling_whisper.py:55-64)."""
+    inc = math.log(10000.0) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2, dtype=torch.float32))
+    t = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
+def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
+    r = _Rng(seed)
+    sd: StateDict = {}
+    D, H, Fd, dh = geo.hidden, geo.heads, geo.ffn, geo.head_dim
+    if geo.family == FAMILY_WHISPER:
+        sd["encoder.conv1.weight"] = r.normal(D, geo.n_mels, 3, std=math.sqrt(2.0 / (geo.n_mels * 3)))
+        sd["encoder.conv1.bias"] = r.normal(D, std=0.05)
+        sd["encoder.conv2.weight"] = r.normal(D, D, 3, std=math.sqrt(2.0 / (D * 3)))
+        sd["encoder.conv2.bias"] = r.normal(D, std=0.05)
+        sd["encoder.embed_positions.weight"] = whisper_sinusoids(geo.max_source_positions, D)
+        for i in range(geo.num_layers):
+            p = f"encoder.layers.{i}"
+            _layer_norm(sd, r, p + ".self_attn_layer_norm", D)
+            _linear(sd, r, p + ".self_attn.q_proj", D, D, gain=1.6)
+            _linear(sd, r, p + ".self_attn.k_proj", D, D, gain=1.6, bias=False)
+            _linear(sd, r, p + ".self_attn.v_proj", D, D)
+            _linear(sd, r, p + ".self_attn.out_proj", D, D)
+            _layer_norm(sd, r, p + ".final_layer_norm", D)
+            _linear(sd, r, p + ".fc1", Fd, D)
+            _linear(sd, r, p + ".fc2", D, Fd)
+        _layer_norm(sd, r, "encoder.layer_norm", D)
+        return sd
+
+    cin = 1
+    for i, (c, k) in enumerate(zip(geo.conv_dim, geo.conv_kernel)):
+        p = f"feature_extractor.conv_layers.{i}"
+        sd[p + ".conv.weight"] = r.normal(c, cin, k, std=math.sqrt(2.0 / (cin * k)))
+        if geo.conv_bias:
+            sd[p + ".conv.bias"] = r.normal(c, std=0.05)
+        _layer_norm(sd, r, p + ".layer_norm", c)
+        cin = c
+    if geo.feat_proj_layer_norm:
+        _layer_norm(sd, r, "feature_projection.layer_norm", cin)
+    _linear(sd, r, "feature_projection.projection", D, cin)
+
+    cg = D // geo.pos_conv_groups
+    v = r.normal(D, cg, geo.pos_conv_kernel, std=math.sqrt(2.0 / (cg * geo.pos_conv_kernel)))
+    g = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt() * r.normal(1, 1, geo.pos_conv_kernel, std=0.1, mean=1.0)
+    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = g
+    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = v
+    sd["encoder.pos_conv_embed.conv.bias"] = r.normal(D, std=0.05)
+    _layer_norm(sd, r, "encoder.layer_norm", D)
+    for i in range(geo.num_layers):
+        p = f"encoder.layers.{i}"
+        a = p + ".attention"
+        _linear(sd, r, a + ".q_proj", D, D, gain=1.6)
+        _linear(sd, r, a + ".k_proj", D, D, gain=1.6)
+        _linear(sd, r, a + ".v_proj", D, D)
+        _linear(sd, r, a + ".out_proj", D, D)
+        if geo.family == FAMILY_WAVLM:
+            sd[a + ".gru_rel_pos_const"] = r.normal(1, H, 1, 1, std=0.2, mean=1.0)
+            sd[a + ".gru_rel_pos_linear.weight"] = r.normal(8, dh, std=0.3)
+            sd[a + ".gru_rel_pos_linear.bias"] = r.normal(8, std=0.3)
+            if i == 0:
+                sd[a + ".rel_attn_embed.weight"] = r.normal(geo.num_buckets, H, std=1.0)
+        _layer_norm(sd, r, p + ".layer_norm", D)
+        _linear(sd, r, p + ".feed_forward.intermediate_dense", Fd, D)
+        _linear(sd, r, p + ".feed_forward.output_dense", D, Fd)
+        _layer_norm(sd, r, p + ".final_layer_norm", D)
+    return sd
+
+
+_STRIP_PREFIXES = ("wavlm.", "wav2vec2.", "hubert.", "model.")
+
+
+def normalize_names(sd: StateDict) -> StateDict:
+    """Strip task-head wrappers (``wav2vec2.`` in *ForCTC checkpoints, ``model.``
+    in WhisperForConditionalGeneration) and drop everything off the encoder path
+    (decoder, lm_head, quantizer, masked_spec_embed)."""
+    out: StateDict = {}
+    for k, v in sd.items():
+        for p in _STRIP_PREFIXES:
+            if k.startswith(p):
+                k = k[len(p):]
+                break
+        if k.startswith(("decoder.", "lm_head", "proj_out", "quantizer", "project_", "masked_spec_embed")):
+            continue
+        out[k] = v.detach().to(torch.float32).contiguous()
+    return out
+
+
+def load_checkpoint(path: str) -> StateDict:
+    """Read a local checkpoint file or directory.  Raises ``OSError`` when nothing
+    loadable is found -- the error class the reference's driver reports as
+    "No pretrained model found" (preprocess_speech.py:115-117)."""
+    candidates = []
+    if os.path.isdir(path):
+        for fn in sorted(os.listdir(path)):
+            if fn.endswith(".safetensors") or fn in ("pytorch_model.bin",):
+                candidates.append(os.path.join(path, fn))
+    elif os.path.isfile(path):
+        candidates.append(path)
+    if not candidates:
+        raise OSError(f"no checkpoint (*.safetensors / pytorch_model.bin) under '{path}'")
+    sd: StateDict = {}
+    for fn in candidates:
+        if fn.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd.update(load_file(fn, device="cpu"))
+        else:
+            sd.update(torch.load(fn, map_location="cpu", weights_only=True))
+    return normalize_names(sd)
+
+
+def state_dict_digest(sd: StateDict) -> str:
+    """Order-independent checksum of a state dict (fixtures record it so a drift of
+    the RNG stream between containers is detected instead of silently compared)."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().contiguous().numpy().tobytes())
+    return h.hexdigest()[:16]
