@@ -1,0 +1,157 @@
+/* ser_hip.h -- C ABI of libserhip.so: hand-written gfx950 (MI355X / CDNA4) kernels
+ * for the SSL embedding-extraction hot path of AI-Unicamp/interspeech_ser.
+ *
+ * The reference has no FFI of its own on this path: preprocessing/
+ * preprocess_speech.py:49-50,66-67 calls  model(**inputs, output_hidden_states=True)
+ * and preprocessing/preprocess_whisper.py:57,71 calls model.encoder(input_features,
+ * output_hidden_states=True); every device op below replaces one implicit
+ * cuDNN/cuBLAS/ATen launch inside those two calls (SURVEY.md 2.3 rows K1..K15,
+ * cited per entry point).  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer unless named host_*;
+ *   - the caller owns all memory; launchers never allocate, free or synchronise;
+ *   - every launcher enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *     0 on success, <0 for an argument/shape error, >0 = hipError_t of the launch;
+ *     ser_last_error() gives the thread-local message of the last non-zero return;
+ *   - launchers are re-entrant (the reference drives its model from 4 Python threads,
+ *     preprocess_speech.py:120-122).
+ *
+ * Data layout (DESIGN.md "HBM layout")
+ *   - utterances are PACKED, never padded: a ragged batch is one [rows, C] matrix
+ *     whose utterance b owns rows frame_offs[b] .. frame_offs[b+1]-1;
+ *   - "act" tensors feed matrix-core GEMMs: bf16, row-major, 1 plane (SER_MODE_BF16) or
+ *     2 planes hi/lo with x ~= hi + lo (SER_MODE_FP32X, the 3-product split that gives
+ *     fp32-grade results on the bf16 MFMA pipe); plane p lives at base + p*plane_stride;
+ *   - the residual stream / hidden states are fp32 row-major [rows, D].
+ */
+#ifndef SER_HIP_H
+#define SER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SER_ABI_VERSION 1
+
+#define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
+#define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
+
+#define SER_ACT_NONE 0
+#define SER_ACT_GELU 1     /* exact erf GELU (ACT2FN["gelu"]) */
+
+int         ser_version(void);
+const char* ser_last_error(void);
+
+/* K1  zero_mean_unit_var_norm (HF feature_extraction_wav2vec2.py:77-97; call site
+ * preprocess_speech.py:48).  wav/out: packed fp32 samples; sample_offs[B+1] (device). */
+int ser_wave_norm(const float* wav, const int64_t* sample_offs, int B, float* out, void* stream);
+
+/* K2  conv layer 0: Conv1d(1,C,k,stride) [+bias] -> LayerNorm(C) -> GELU
+ * (HF modeling_wavlm.py:696-720).  One output row per frame.
+ * w: [C,k] fp32; bias may be NULL; out: act [rows,C]. C multiple of 64, C <= 1024, k <= 16. */
+int ser_conv0_ln_gelu(const float* wav_norm, const int64_t* sample_offs, const int32_t* frame_offs,
+                      int B, const float* w, const float* bias, const float* ln_g, const float* ln_b,
+                      void* out, int64_t out_plane_stride, int mode,
+                      int C, int k, int stride, int total_rows, void* stream);
+
+/* K3/K4/K5/K7/K10/K11/K12/K14  one matrix-core GEMM with an implicit-convolution
+ * row map and a fused epilogue:   C[m,n] = sum_k A(m,k) * W[n,k]
+ *   A(m,k)  = A[ a_row(m)*8 + (k / kc)*ldj + (k % kc) ]   (kc == 0: plain row-major, lda)
+ *   a_row(m)= a_rowoff ? a_rowoff[m] : m*lda/8             (units of 8 elements = 16 bytes)
+ * so that a strided Conv1d over a channels-last [frames, C] matrix (HF modeling_wavlm.py:
+ * 696-720, modeling_whisper.py:618-619), the grouped positional conv (:48-90) and every
+ * nn.Linear (:133-136, :288-294) are the same kernel.  Epilogue order:
+ *   v = acc + bias[n];  v = act(v);  v += residual[(m % res_row_mod or m)*ldr + n];
+ *   out_f32[m*ldo_f32 + n] = v;   out_act[out_row(m)*ldo_act + n] = split(v)
+ * Requirements: K % 64 == 0, kc % 64 == 0, N % 8 == 0, all row starts 16-byte aligned. */
+typedef struct ser_gemm_args {
+    const void*    A;              /* act (bf16 planes) */
+    int64_t        a_plane_stride; /* elements between hi and lo plane (FP32X) */
+    const int32_t* a_rowoff;       /* [M] or NULL */
+    int64_t        lda;            /* elements, used when a_rowoff == NULL */
+    int32_t        kc;             /* K-chunk length of the conv map, 0 = none */
+    int64_t        ldj;            /* element step between K-chunks (conv tap stride) */
+    const void*    W;              /* bf16 [groups][N][K] (+ lo plane) */
+    int64_t        w_plane_stride;
+    int32_t        M, N, K;
+    int32_t        groups;         /* blockIdx.y; 1 for dense */
+    int64_t        a_group_stride; /* elements added to A per group (column offset) */
+    int64_t        w_group_stride; /* elements per group in W */
+    int32_t        c_group_stride; /* output columns per group */
+    int32_t        mode;           /* SER_MODE_* */
+    const float*   bias;           /* [groups*N] or NULL */
+    int32_t        act;            /* SER_ACT_* */
+    const float*   residual;       /* fp32 or NULL */
+    int64_t        ldr;
+    int32_t        res_row_mod;    /* 0: row m; >0: row m % res_row_mod (Whisper positions) */
+    float*         out_f32;        /* may be NULL */
+    int64_t        ldo_f32;
+    void*          out_act;        /* may be NULL */
+    int64_t        ldo_act;
+    int64_t        out_plane_stride;
+    const int32_t* out_rowmap;     /* [M] row index in out_act, or NULL (identity) */
+} ser_gemm_args;
+int ser_gemm(const ser_gemm_args* args, void* stream);
+
+/* K6  LayerNorm over the last dim (+ optional GELU), fp32 in
+ * (HF modeling_wavlm.py:357,366,513; conv-stack LN :716-718).  Either output may be NULL. */
+int ser_layernorm(const float* x, int64_t ldx, const float* g, const float* b, float eps, int gelu,
+                  float* out_f32, int64_t ldo_f32, void* out_act, int64_t ldo_act, int64_t out_plane_stride,
+                  int mode, int rows, int D, void* stream);
+
+/* K8a WavLM relative-position bias as a [H, 2*T-1] table: column (key-query)+(T-1)
+ * (compute_bias + _relative_positions_bucket, HF modeling_wavlm.py:243-271). */
+int ser_wavlm_bias_table(const float* rel_attn_embed /*[num_buckets,H]*/, float* table /*[H,2T-1]*/,
+                         int T, int H, int num_buckets, int max_distance, void* stream);
+
+/* K8b WavLM GRU gate (HF modeling_wavlm.py:167-180): gate[row,h] from the layer-normed act x. */
+int ser_wavlm_gate(const void* x_ln, int64_t ldx, int64_t plane_stride, int mode,
+                   const float* w8 /*[8,dh]*/, const float* b8 /*[8]*/, const float* gru_const /*[H]*/,
+                   float* gate /*[rows,H]*/, int rows, int H, int dh, void* stream);
+
+/* K9  fused attention over a packed ragged batch:
+ *   out[q,:] = softmax_k( q.k * scale + gate[q,h] * table[h, k-q+table_T-1] ) v
+ * q/k/v are column blocks of one act matrix [rows, ld] (packed QKV projection output);
+ * utterance b owns rows frame_offs[b] .. frame_offs[b+1]-1 and attends only to itself
+ * (batch-of-one semantics of preprocess_speech.py:76-81, so no key-padding mask exists).
+ * WavLM: HF modeling_wavlm.py:188-241; wav2vec2/HuBERT: modeling_wav2vec2.py:438-548;
+ * Whisper: modeling_whisper.py:284-357 (pass scale = dh^-0.5, identical in exact arithmetic).
+ * dh in {64, 80, 96, 120, 128}; table/gate NULL for plain attention. */
+int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
+                  const int32_t* frame_offs /*[B+1] device*/, int B, int max_frames,
+                  const float* table, int table_T, const float* gate,
+                  void* out, int64_t ldo, int64_t out_plane_stride,
+                  int H, int dh, float scale, int mode, void* stream);
+
+/* K13 Whisper log-mel front end (HF feature_extraction_whisper.py:135-169): packed fp32
+ * samples -> [B, n_mels, 3000] fp32 (zero-pad/truncate to 480000, reflect pad, Hann,
+ * 400-pt DFT power, mel, log10, per-utterance max-8 floor, (x+4)/4).
+ * mel: [201, n_mels] fp32.  work: ser_workspace_bytes(SER_WS_LOGMEL, B, ...) bytes. */
+int ser_logmel_whisper(const float* wav, const int64_t* sample_offs, int B, const float* mel, int n_mels,
+                       float* out, void* work, void* stream);
+
+/* fp32 [rows, C] -> act (bf16 / hi+lo planes), optional transpose of a [B, C, T] input
+ * into channels-last rows with `halo` zero rows before and after each utterance
+ * (feeds the Whisper stem convs, HF modeling_whisper.py:618-619). */
+int ser_pack_act(const float* x, int B, int C, int T, int halo, void* out, int64_t ldo,
+                 int64_t out_plane_stride, int mode, void* stream);
+
+/* K15 mean of 4 fp32 states (--use_average y; preprocess_speech.py:52-63). */
+int ser_mean4(const float* s0, const float* s1, const float* s2, const float* s3, float* out,
+              int64_t n, void* stream);
+
+/* weights: fp32 -> bf16 hi (+ lo) planes, done once at load. */
+int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, int64_t n, void* stream);
+
+#define SER_WS_LOGMEL 1
+size_t ser_workspace_bytes(int op, int B, int T, int D, int H, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SER_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libserhip.so (the C ABI in include/ser_hip.h).
+
+There is exactly one compute backend.  If the library cannot be loaded the
+import of this module raises: the product never falls back to PyTorch ops or to
+the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libserhip.so")
+
+MODE_BF16 = 1
+MODE_FP32X = 2
+ACT_NONE = 0
+ACT_GELU = 1
+WS_LOGMEL = 1
+ABI_VERSION = 1
+
+c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    """Mirror of ``ser_gemm_args`` (include/ser_hip.h); field order is ABI."""
+    _fields_ = [
+        ("A", c_void_p), ("a_plane_stride", c_i64), ("a_rowoff", c_void_p), ("lda", c_i64),
+        ("kc", C.c_int32), ("ldj", c_i64),
+        ("W", c_void_p), ("w_plane_stride", c_i64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
+        ("a_group_stride", c_i64), ("w_group_stride", c_i64), ("c_group_stride", C.c_int32),
+        ("mode", C.c_int32), ("bias", c_void_p), ("act", C.c_int32),
+        ("residual", c_void_p), ("ldr", c_i64), ("res_row_mod", C.c_int32),
+        ("out_f32", c_void_p), ("ldo_f32", c_i64),
+        ("out_act", c_void_p), ("ldo_act", c_i64), ("out_plane_stride", c_i64),
+        ("out_rowmap", c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "ser_version": (c_int, []),
+    "ser_last_error": (C.c_char_p, []),
+    "ser_wave_norm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ser_conv0_ln_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ser_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "ser_layernorm": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_i64, c_void_p, c_i64,
+                              c_i64, c_int, c_int, c_int, c_void_p]),
+    "ser_wavlm_bias_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ser_wavlm_gate": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                               c_int, c_void_p]),
+    "ser_attention": (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                              c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_int, c_void_p]),
+    "ser_logmel_whisper": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "ser_pack_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "ser_mean4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "ser_split_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p]),
+    "ser_workspace_bytes": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class SerHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise SerHipError(
+            f"{LIB_PATH} is missing: build it with `make -C interspeech_ser_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()').  There is no fallback backend.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.ser_version()
+    if got != ABI_VERSION:
+        raise SerHipError(f"libserhip ABI version {got} != expected {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Turn a non-zero launcher return into a Python exception; the drivers'
+    per-utterance try/except then logs and skips (preprocess_speech.py:46,72-73)."""
+    if rc != 0:
+        msg = lib.ser_last_error()
+        raise SerHipError(f"{what or 'libserhip'} failed (rc={rc}): {msg.decode() if msg else ''}")

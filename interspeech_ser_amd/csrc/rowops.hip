@@ -1,0 +1,378 @@
+// HBM-bound row kernels: waveform normalisation (K1), conv layer 0 + LayerNorm + GELU (K2),
+// LayerNorm (K6), WavLM bias table / GRU gate (K8), state mean (K15), bf16 splitting.
+// One 64-lane wave owns one row; reductions are DPP/shuffle butterflies, loads/stores 16 B/lane.
+#include "ser_common.h"
+
+// ------------------------------------------------------------------------------- K1
+// One 1024-thread block per utterance, three sweeps (sum, squared deviation, write).
+__global__ __launch_bounds__(1024) void wave_norm_kernel(const float* __restrict__ wav,
+                                                         const int64_t* __restrict__ offs, float* __restrict__ out) {
+    __shared__ double red[16];
+    __shared__ float stat[2];
+    const int b = blockIdx.x;
+    const int64_t s0 = offs[b], n = offs[b + 1] - s0;
+    const float* x = wav + s0;
+    float* y = out + s0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    double acc = 0.0;
+    for (int64_t i = tid; i < n; i += 1024) acc += (double)x[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        stat[0] = (float)(t / (double)n);
+    }
+    __syncthreads();
+    const float mean = stat[0];
+    acc = 0.0;
+    for (int64_t i = tid; i < n; i += 1024) { const float d = x[i] - mean; acc += (double)(d * d); }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __syncthreads();
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        stat[1] = sqrtf((float)(t / (double)n) + 1e-7f);
+    }
+    __syncthreads();
+    const float sd = stat[1];
+    for (int64_t i = tid; i < n; i += 1024) y[i] = (x[i] - mean) / sd;
+}
+
+extern "C" int ser_wave_norm(const float* wav, const int64_t* sample_offs, int B, float* out, void* stream) {
+    if (!wav || !sample_offs || !out || B <= 0) return ser_fail(-1, "ser_wave_norm: bad arguments");
+    hipLaunchKernelGGL(wave_norm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, wav, sample_offs, out);
+    return ser_check_launch("ser_wave_norm");
+}
+
+// ------------------------------------------------------------------------------- K2
+// Wave per frame: lane owns CPL consecutive channels, weights live in registers.
+template <int CPL, int MODE>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const int64_t* __restrict__ soffs,
+                                                    const int32_t* __restrict__ foffs, int B,
+                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                    const float* __restrict__ lg, const float* __restrict__ lb,
+                                                    unsigned short* __restrict__ out, int64_t plane,
+                                                    int k, int stride, int rows) {
+    constexpr int C = CPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int wglobal = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int c0 = lane * CPL;
+    float wr[CPL][16];
+    float br[CPL], gr[CPL], be[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wr[i][j] = j < k ? w[(c0 + i) * k + j] : 0.f;
+        br[i] = bias ? bias[c0 + i] : 0.f;
+        gr[i] = lg[c0 + i];
+        be[i] = lb[c0 + i];
+    }
+    for (int row = wglobal; row < rows; row += nwaves) {
+        int b = 0;
+        while (b + 1 < B && foffs[b + 1] <= row) ++b;            // B is small; wave-uniform scalar walk
+        const int t = row - foffs[b];
+        const float* xs = x + soffs[b] + (int64_t)t * stride;
+        const float xv = lane < k ? xs[lane] : 0.f;
+        float v[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) v[i] = br[i];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < k) {
+                const float xj = __shfl(xv, j, 64);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) v[i] = fmaf(wr[i][j], xj, v[i]);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) s += v[i];
+        const float mean = wave_sum(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { const float d = v[i] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) v[i] = gelu_erf((v[i] - mean) * rstd * gr[i] + be[i]);
+        unsigned short* dst = out + (int64_t)row * C + c0;
+        if (CPL >= 4) {
+#pragma unroll
+            for (int i = 0; i < CPL; i += 4) store_act4<MODE>(dst + i, plane, v[i], v[i + 1], v[i + 2], v[i + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                unsigned short h, l;
+                split_bf(v[i], h, l);
+                dst[i] = h;
+                if (MODE == SER_MODE_FP32X) dst[plane + i] = l;
+            }
+        }
+    }
+}
+
+extern "C" int ser_conv0_ln_gelu(const float* wav_norm, const int64_t* sample_offs, const int32_t* frame_offs,
+                                 int B, const float* w, const float* bias, const float* ln_g, const float* ln_b,
+                                 void* out, int64_t out_plane_stride, int mode, int C, int k, int stride,
+                                 int total_rows, void* stream) {
+    if (!wav_norm || !sample_offs || !frame_offs || !w || !ln_g || !ln_b || !out) return ser_fail(-1, "ser_conv0: null pointer");
+    if (k < 1 || k > 16 || stride < 1 || total_rows <= 0 || B <= 0) return ser_fail(-2, "ser_conv0: bad k/stride/rows");
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_conv0: bad mode");
+    int blocks = (total_rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    dim3 grid(blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* o = (unsigned short*)out;
+#define LAUNCH(CPL)                                                                                              \
+    do {                                                                                                         \
+        if (mode == SER_MODE_BF16)                                                                               \
+            hipLaunchKernelGGL((conv0_kernel<CPL, SER_MODE_BF16>), grid, block, 0, s, wav_norm, sample_offs,     \
+                               frame_offs, B, w, bias, ln_g, ln_b, o, out_plane_stride, k, stride, total_rows); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((conv0_kernel<CPL, SER_MODE_FP32X>), grid, block, 0, s, wav_norm, sample_offs,    \
+                               frame_offs, B, w, bias, ln_g, ln_b, o, out_plane_stride, k, stride, total_rows); \
+    } while (0)
+    switch (C) {
+        case 64: LAUNCH(1); break;
+        case 128: LAUNCH(2); break;
+        case 256: LAUNCH(4); break;
+        case 512: LAUNCH(8); break;
+        default: return ser_fail(-4, "ser_conv0: C=%d unsupported (64/128/256/512)", C);
+    }
+#undef LAUNCH
+    return ser_check_launch("ser_conv0_ln_gelu");
+}
+
+// ------------------------------------------------------------------------------- K6
+// Wave per row, row kept in registers (D <= 2048), two-pass mean / variance.
+template <int MODE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        float eps, int gelu, float* __restrict__ of, int64_t ldof,
+                                                        unsigned short* __restrict__ oa, int64_t ldoa, int64_t plane,
+                                                        int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) { v[i] = *(const f32x4*)(xr + c); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+        else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+                y[j] = gelu ? gelu_erf(t) : t;
+            }
+            if (of) *(f32x4*)(of + (int64_t)row * ldof + c) = y;
+            if (oa) store_act4<MODE>(oa + (int64_t)row * ldoa + c, plane, y[0], y[1], y[2], y[3]);
+        }
+    }
+}
+
+extern "C" int ser_layernorm(const float* x, int64_t ldx, const float* g, const float* b, float eps, int gelu,
+                             float* out_f32, int64_t ldo_f32, void* out_act, int64_t ldo_act,
+                             int64_t out_plane_stride, int mode, int rows, int D, void* stream) {
+    if (!x || !g || !b || (!out_f32 && !out_act)) return ser_fail(-1, "ser_layernorm: null pointer");
+    if (D % 4 || D > 2048 || D <= 0 || rows <= 0) return ser_fail(-2, "ser_layernorm: D=%d rows=%d unsupported", D, rows);
+    if ((ldx % 4) || (out_f32 && ldo_f32 % 4) || (out_act && ldo_act % 4)) return ser_fail(-3, "ser_layernorm: pitches must be multiples of 4");
+    dim3 grid((rows + 3) / 4), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
+                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
+    else if (mode == SER_MODE_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
+                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
+    else return ser_fail(-4, "ser_layernorm: bad mode %d", mode);
+    return ser_check_launch("ser_layernorm");
+}
+
+// ------------------------------------------------------------------------------ K8a
+__global__ void bias_table_kernel(const float* __restrict__ emb, float* __restrict__ table, int T, int H,
+                                  int num_buckets, int max_distance) {
+    const int W = 2 * T - 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= W) return;
+    const int rel = idx - (T - 1);                               // key - query
+    const int nb = num_buckets / 2, max_exact = nb / 2;
+    const int n = rel < 0 ? -rel : rel;
+    int bucket = rel > 0 ? nb : 0;
+    if (n < max_exact) bucket += n;
+    else {
+        // float32 arithmetic in the order HF uses: log(n/max_exact) / log(max_distance/max_exact) * (nb-max_exact)
+        float v = logf((float)n / (float)max_exact);
+        v = v / (float)log((double)max_distance / (double)max_exact);
+        v = v * (float)(nb - max_exact);
+        int big = (int)((float)max_exact + v);
+        bucket += big < nb - 1 ? big : nb - 1;
+    }
+    for (int h = 0; h < H; ++h) table[(int64_t)h * W + idx] = emb[(int64_t)bucket * H + h];
+}
+
+extern "C" int ser_wavlm_bias_table(const float* rel_attn_embed, float* table, int T, int H, int num_buckets,
+                                    int max_distance, void* stream) {
+    if (!rel_attn_embed || !table || T <= 0 || H <= 0) return ser_fail(-1, "ser_wavlm_bias_table: bad arguments");
+    const int W = 2 * T - 1;
+    hipLaunchKernelGGL(bias_table_kernel, dim3((W + 255) / 256), dim3(256), 0, (hipStream_t)stream, rel_attn_embed,
+                       table, T, H, num_buckets, max_distance);
+    return ser_check_launch("ser_wavlm_bias_table");
+}
+
+// ------------------------------------------------------------------------------ K8b
+// gate[row,h] = a*(b*const_h - 1) + 2,  (a,b) = sigmoid(sum_{j<4} (w_j.x + b_j)), sigmoid(sum_{j>=4} ...)
+template <int MODE>
+__global__ __launch_bounds__(256) void gate_kernel(const unsigned short* __restrict__ x, int64_t ldx, int64_t plane,
+                                                   const float* __restrict__ w8, const float* __restrict__ b8,
+                                                   const float* __restrict__ gconst, float* __restrict__ gate,
+                                                   int rows, int H, int dh) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    // lane covers columns lane and lane+64 of a head (dh <= 128)
+    float wa0 = 0.f, wb0 = 0.f, wa1 = 0.f, wb1 = 0.f;
+    if (lane < dh) {
+        wa0 = (w8[0 * dh + lane] + w8[1 * dh + lane]) + (w8[2 * dh + lane] + w8[3 * dh + lane]);
+        wb0 = (w8[4 * dh + lane] + w8[5 * dh + lane]) + (w8[6 * dh + lane] + w8[7 * dh + lane]);
+    }
+    if (lane + 64 < dh) {
+        const int c = lane + 64;
+        wa1 = (w8[0 * dh + c] + w8[1 * dh + c]) + (w8[2 * dh + c] + w8[3 * dh + c]);
+        wb1 = (w8[4 * dh + c] + w8[5 * dh + c]) + (w8[6 * dh + c] + w8[7 * dh + c]);
+    }
+    const float ba = (b8[0] + b8[1]) + (b8[2] + b8[3]);
+    const float bb = (b8[4] + b8[5]) + (b8[6] + b8[7]);
+    const unsigned short* xr = x + (int64_t)row * ldx;
+    for (int h = 0; h < H; ++h) {
+        float x0 = 0.f, x1 = 0.f;
+        if (lane < dh) {
+            x0 = bf2f(xr[h * dh + lane]);
+            if (MODE == SER_MODE_FP32X) x0 += bf2f(xr[plane + h * dh + lane]);
+        }
+        if (lane + 64 < dh) {
+            x1 = bf2f(xr[h * dh + lane + 64]);
+            if (MODE == SER_MODE_FP32X) x1 += bf2f(xr[plane + h * dh + lane + 64]);
+        }
+        const float pa = wave_sum(x0 * wa0 + x1 * wa1) + ba;
+        const float pb = wave_sum(x0 * wb0 + x1 * wb1) + bb;
+        if (lane == 0) {
+            const float a = 1.f / (1.f + expf(-pa));
+            const float b = 1.f / (1.f + expf(-pb));
+            gate[(int64_t)row * H + h] = a * (b * gconst[h] - 1.f) + 2.f;
+        }
+    }
+}
+
+extern "C" int ser_wavlm_gate(const void* x_ln, int64_t ldx, int64_t plane_stride, int mode, const float* w8,
+                              const float* b8, const float* gru_const, float* gate, int rows, int H, int dh,
+                              void* stream) {
+    if (!x_ln || !w8 || !b8 || !gru_const || !gate) return ser_fail(-1, "ser_wavlm_gate: null pointer");
+    if (dh > 128 || dh <= 0 || rows <= 0) return ser_fail(-2, "ser_wavlm_gate: dh=%d unsupported", dh);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(gate_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, (const unsigned short*)x_ln,
+                           ldx, plane_stride, w8, b8, gru_const, gate, rows, H, dh);
+    else
+        hipLaunchKernelGGL(gate_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, (const unsigned short*)x_ln,
+                           ldx, plane_stride, w8, b8, gru_const, gate, rows, H, dh);
+    return ser_check_launch("ser_wavlm_gate");
+}
+
+// ------------------------------------------------------------------------------ K15
+__global__ void mean4_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                             const float* __restrict__ d, float* __restrict__ o, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // torch.mean(torch.stack(hs[-4:]), dim=0): sequential sum then divide
+    if (i < n) o[i] = (((a[i] + b[i]) + c[i]) + d[i]) / 4.0f;
+}
+
+extern "C" int ser_mean4(const float* s0, const float* s1, const float* s2, const float* s3, float* out, int64_t n,
+                         void* stream) {
+    if (!s0 || !s1 || !s2 || !s3 || !out || n <= 0) return ser_fail(-1, "ser_mean4: bad arguments");
+    hipLaunchKernelGGL(mean4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s0, s1, s2,
+                       s3, out, n);
+    return ser_check_launch("ser_mean4");
+}
+
+// ------------------------------------------------------------------- weights / packing
+__global__ void split_kernel(const float* __restrict__ x, unsigned short* __restrict__ o, int64_t plane, int two,
+                             int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        unsigned short h, l;
+        split_bf(x[i], h, l);
+        o[i] = h;
+        if (two) o[plane + i] = l;
+    }
+}
+
+extern "C" int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, int64_t n, void* stream) {
+    if (!x || !out || n <= 0) return ser_fail(-1, "ser_split_bf16: bad arguments");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short*)out, plane_stride, mode == SER_MODE_FP32X ? 1 : 0, n);
+    return ser_check_launch("ser_split_bf16");
+}
+
+// [B, C, T] fp32 -> channels-last act rows with `halo` zero rows around each utterance:
+// utterance b occupies rows b*(T+2*halo) .. ; rows [halo, halo+T) carry data.
+template <int MODE>
+__global__ void pack_act_kernel(const float* __restrict__ x, int B, int C, int T, int halo,
+                                unsigned short* __restrict__ o, int64_t ldo, int64_t plane) {
+    const int Tp = T + 2 * halo;
+    const int64_t total = (int64_t)B * Tp * (C / 4);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int tp = (int)(i % Tp);
+    const int64_t r = i / Tp;
+    const int cg = (int)(r % (C / 4));
+    const int b = (int)(r / (C / 4));
+    const int t = tp - halo;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && t < T) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = x[((int64_t)b * C + cg * 4 + j) * T + t];
+    }
+    store_act4<MODE>(o + ((int64_t)b * Tp + tp) * ldo + cg * 4, plane, v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int ser_pack_act(const float* x, int B, int C, int T, int halo, void* out, int64_t ldo,
+                            int64_t out_plane_stride, int mode, void* stream) {
+    if (!x || !out || B <= 0 || C % 4 || T <= 0 || halo < 0) return ser_fail(-1, "ser_pack_act: bad arguments");
+    const int64_t total = (int64_t)B * (T + 2 * halo) * (C / 4);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(pack_act_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
+                           (unsigned short*)out, ldo, out_plane_stride);
+    else
+        hipLaunchKernelGGL(pack_act_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
+                           (unsigned short*)out, ldo, out_plane_stride);
+    return ser_check_launch("ser_pack_act");
+}

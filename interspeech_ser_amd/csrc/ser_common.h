@@ -1,0 +1,84 @@
+// Shared device helpers for libserhip (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ser_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define SER_WAVE 64
+
+// host-side error plumbing (capi.hip)
+int ser_fail(int code, const char* fmt, ...);
+int ser_check_launch(const char* what);
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+    return __builtin_bit_cast(unsigned short, (__bf16)x);      // v_cvt_pk_bf16_f32: RNE, NaN-safe
+}
+__device__ __forceinline__ float bf2f(unsigned short h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned int pack_bf2(float a, float b) {
+    return (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
+}
+// x ~= hi + lo with both halves bf16: 16 significand bits survive.
+__device__ __forceinline__ void split_bf(float x, unsigned short& hi, unsigned short& lo) {
+    hi = f2bf(x);
+    lo = f2bf(x - bf2f(hi));
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Store n (multiple of 4, <= 16) consecutive fp32 values as act (bf16 hi [+ lo]) at element
+// pointer `dst` (8-byte aligned).  `plane` = element distance to the lo plane.
+template <int MODE>
+__device__ __forceinline__ void store_act4(unsigned short* dst, int64_t plane, float a, float b, float c, float d) {
+    if (MODE == SER_MODE_BF16) {
+        u32x2 v = {pack_bf2(a, b), pack_bf2(c, d)};
+        *(u32x2*)dst = v;
+    } else {
+        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf(a, h0, l0); split_bf(b, h1, l1); split_bf(c, h2, l2); split_bf(d, h3, l3);
+        u32x2 vh = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+        u32x2 vl = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+        *(u32x2*)dst = vh;
+        *(u32x2*)(dst + plane) = vl;
+    }
+}
+
+// Load 8 consecutive act elements as fp32 (hi [+ lo]).
+template <int MODE>
+__device__ __forceinline__ void load_act8(const unsigned short* src, int64_t plane, float (&v)[8]) {
+    u32x4 h = *(const u32x4*)src;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(h[i] << 16);
+        v[2 * i + 1] = __uint_as_float(h[i] & 0xffff0000u);
+    }
+    if (MODE == SER_MODE_FP32X) {
+        u32x4 l = *(const u32x4*)(src + plane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] += __uint_as_float(l[i] << 16);
+            v[2 * i + 1] += __uint_as_float(l[i] & 0xffff0000u);
+        }
+    }
+}

@@ -1,0 +1,519 @@
+"""Host-side encoders: the drop-in for the reference's model call.
+
+The reference does (preprocess_speech.py:49-50,66-67 / preprocess_whisper.py:57,71)
+
+    hidden_states = model(**inputs, output_hidden_states=True).hidden_states
+    hidden_states = model.encoder(input_features, output_hidden_states=True).hidden_states
+
+one utterance at a time.  ``SpeechEncoder.forward`` / ``WhisperEncoder.forward``
+take a *ragged batch* of raw waveforms and return the same L+1 hidden states for
+every utterance, computed entirely by libserhip's gfx950 kernels.  PyTorch is used
+for device memory, H2D/D2H copies and the stream handle only.
+
+HBM layout: utterances are packed, never padded -- a batch is one ``[rows, C]``
+matrix and ``frame_offs[b]`` is utterance b's first row.  Packed rows make a batched
+run arithmetically identical to the reference's batch-of-one loop (no padding frames
+exist, so no attention / conv masking is needed) and waste no FLOPs on padding.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check, lib
+from .config import EncoderGeometry, FAMILY_WAVLM, FAMILY_WHISPER
+
+MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Act:
+    """bf16 GEMM operand with 1 (bf16) or 2 (hi/lo) planes: tensor [planes, rows, cols]."""
+
+    def __init__(self, rows: int, cols: int, planes: int, device, zero: bool = False, extra_rows: int = 0):
+        alloc = torch.zeros if zero else torch.empty
+        self.t = alloc((planes, rows + extra_rows, cols), dtype=torch.bfloat16, device=device)
+        self.rows, self.cols, self.planes = rows, cols, planes
+        self.plane_stride = (rows + extra_rows) * cols
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def float(self) -> torch.Tensor:
+        """fp32 view for tests (hi + lo)."""
+        return self.t[:, : self.rows].float().sum(dim=0)
+
+
+@dataclass
+class Linear:
+    w: torch.Tensor            # [planes, N, K] bf16
+    b: Optional[torch.Tensor]  # [N] fp32
+    N: int
+    K: int
+
+
+class HiddenStates:
+    """What ``.hidden_states`` is in the reference: L+1 states per utterance.
+    ``states`` is one fp32 tensor [L+1, rows, D]; utterance b owns rows
+    frame_offs[b]:frame_offs[b+1] (crop to the true frame count is implicit)."""
+
+    def __init__(self, states: torch.Tensor, frame_offs: Sequence[int]):
+        self.states = states
+        self.frame_offs = list(int(x) for x in frame_offs)
+
+    def __len__(self) -> int:
+        return self.states.shape[0]
+
+    @property
+    def batch(self) -> int:
+        return len(self.frame_offs) - 1
+
+    def utterance(self, b: int, layer: int) -> torch.Tensor:
+        return self.states[layer, self.frame_offs[b]: self.frame_offs[b + 1]]
+
+    def frames(self, b: int) -> int:
+        return self.frame_offs[b + 1] - self.frame_offs[b]
+
+
+class _EncoderBase:
+    def __init__(self, geo: EncoderGeometry, device, mode: str):
+        if mode not in MODES:
+            raise ValueError(f"mode must be one of {list(MODES)}")
+        if not torch.cuda.is_available():
+            raise _lib.SerHipError("no HIP device visible: the extraction path has no CPU fallback")
+        self.geo = geo
+        self.device = torch.device(device)
+        self.mode_name = mode
+        self.mode = MODES[mode]
+        self.planes = 2 if mode == "fp32x" else 1
+        self._cache: Dict = {}
+
+    # ------------------------------------------------------------------ weights
+    def _dev_f32(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(torch.float32).contiguous().to(self.device)
+
+    def _linear(self, w: torch.Tensor, b: Optional[torch.Tensor]) -> Linear:
+        """fp32 [N, K] -> bf16 hi (+ lo) planes on the device (ser_split_bf16)."""
+        w = w.detach().to(torch.float32).contiguous()
+        N, K = w.shape
+        src = w.to(self.device)
+        out = torch.empty((self.planes, N, K), dtype=torch.bfloat16, device=self.device)
+        check(lib.ser_split_bf16(src.data_ptr(), out.data_ptr(), N * K, self.mode, N * K, _stream()), "ser_split_bf16")
+        torch.cuda.current_stream().synchronize()
+        return Linear(out, None if b is None else self._dev_f32(b), N, K)
+
+    def _new_act(self, rows, cols, zero=False, extra_rows=0) -> Act:
+        return Act(rows, cols, self.planes, self.device, zero=zero, extra_rows=extra_rows)
+
+    # ------------------------------------------------------------------ launchers
+    def _gemm(self, a: Act, lin: Linear, M: int, *, a_rowoff=None, lda=None, kc=0, ldj=0, groups=1,
+              a_group_stride=0, w_group_stride=0, c_group_stride=0, N=None, K=None, act=_lib.ACT_NONE,
+              residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
+              out_rowmap=None, a_ptr_offset=0):
+        g = GemmArgs()
+        g.A = a.ptr + a_ptr_offset
+        g.a_plane_stride = a.plane_stride
+        g.a_rowoff = _ptr(a_rowoff)
+        g.lda = a.cols if lda is None else lda
+        g.kc, g.ldj = kc, ldj
+        g.W = lin.w.data_ptr()
+        g.w_plane_stride = lin.w.shape[1] * lin.w.shape[2]
+        g.M, g.N, g.K = M, (lin.N if N is None else N), (lin.K if K is None else K)
+        g.groups = groups
+        g.a_group_stride, g.w_group_stride, g.c_group_stride = a_group_stride, w_group_stride, c_group_stride
+        g.mode = self.mode
+        g.bias = _ptr(lin.b)
+        g.act = act
+        g.residual = _ptr(residual)
+        g.ldr = ldr
+        g.res_row_mod = res_row_mod
+        g.out_f32 = _ptr(out_f32)
+        g.ldo_f32 = ldo_f32
+        g.out_act = None if out_act is None else out_act.ptr
+        g.ldo_act = 0 if out_act is None else out_act.cols
+        g.out_plane_stride = 0 if out_act is None else out_act.plane_stride
+        g.out_rowmap = _ptr(out_rowmap)
+        check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
+
+    def _layernorm(self, x: torch.Tensor, ldx: int, ln, rows: int, D: int, *, gelu=False, out_f32=None,
+                   out_act: Optional[Act] = None, eps=None):
+        g, b = ln
+        check(lib.ser_layernorm(x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(),
+                                float(self.geo.layer_norm_eps if eps is None else eps), int(gelu),
+                                _ptr(out_f32), D if out_f32 is not None else 0,
+                                None if out_act is None else out_act.ptr,
+                                0 if out_act is None else out_act.cols,
+                                0 if out_act is None else out_act.plane_stride,
+                                self.mode, rows, D, _stream()), "ser_layernorm")
+
+    def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None):
+        D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
+        check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
+                                max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
+                                H, dh, float(dh ** -0.5), self.mode, _stream()), "ser_attention")
+
+    def _ln_pair(self, sd, prefix):
+        return (self._dev_f32(sd[prefix + ".weight"]), self._dev_f32(sd[prefix + ".bias"]))
+
+
+def _fold_weight_norm(sd) -> torch.Tensor:
+    """w = g * v / ||v||_(dims 0,1) per tap (HF modeling_wavlm.py:48-75), at load time."""
+    base = "encoder.pos_conv_embed.conv."
+    if base + "parametrizations.weight.original0" in sd:
+        g, v = sd[base + "parametrizations.weight.original0"], sd[base + "parametrizations.weight.original1"]
+    elif base + "weight_g" in sd:
+        g, v = sd[base + "weight_g"], sd[base + "weight_v"]
+    else:
+        return sd[base + "weight"].float()
+    g, v = g.float(), v.float()
+    return v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+
+
+class SpeechEncoder(_EncoderBase):
+    """WavLM / wav2vec2 / HuBERT (stable-LayerNorm, layer-norm conv stack) on libserhip."""
+
+    def __init__(self, geo: EncoderGeometry, state_dict, device="cuda:0", mode: str = "bf16"):
+        super().__init__(geo, device, mode)
+        if geo.family == FAMILY_WHISPER:
+            raise ValueError("use WhisperEncoder for the whisper family")
+        if not geo.feat_proj_layer_norm:
+            raise NotImplementedError("feat_proj_layer_norm=False checkpoints are not supported")
+        sd = state_dict
+        D, C0 = geo.hidden, geo.conv_dim[0]
+        if any(c != C0 for c in geo.conv_dim):
+            raise NotImplementedError("conv_dim must be uniform")
+        # conv stack
+        p0 = "feature_extractor.conv_layers.0"
+        self.conv0_w = self._dev_f32(sd[p0 + ".conv.weight"].reshape(C0, geo.conv_kernel[0]))
+        self.conv0_b = self._dev_f32(sd[p0 + ".conv.bias"]) if geo.conv_bias else None
+        self.conv_ln = [self._ln_pair(sd, f"feature_extractor.conv_layers.{i}.layer_norm") for i in range(len(geo.conv_dim))]
+        self.convs: List[Linear] = []
+        for i in range(1, len(geo.conv_dim)):
+            p = f"feature_extractor.conv_layers.{i}.conv"
+            w = sd[p + ".weight"].float()                                  # [Cout, Cin, k]
+            w2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)                # K index = tap*Cin + c
+            self.convs.append(self._linear(w2, sd[p + ".bias"] if geo.conv_bias else None))
+        self.proj_ln = self._ln_pair(sd, "feature_projection.layer_norm")
+        self.proj = self._linear(sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"])
+        # positional conv: per group [Cg out][tap][Cg in padded to a multiple of 64]
+        G, k = geo.pos_conv_groups, geo.pos_conv_kernel
+        Cg = D // G
+        self.pos_cg, self.pos_kc = Cg, ((Cg + 63) // 64) * 64
+        w = _fold_weight_norm(sd)                                          # [D, Cg, k]
+        wp = torch.zeros((G, Cg, k, self.pos_kc), dtype=torch.float32)
+        wp[:, :, :, :Cg] = w.view(G, Cg, Cg, k).permute(0, 1, 3, 2)
+        self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"])
+        self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
+        self.layers = []
+        for i in range(geo.num_layers):
+            p = f"encoder.layers.{i}"
+            a = p + ".attention"
+            qkv_w = torch.cat([sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]], 0)
+            qkv_b = torch.cat([sd[a + ".q_proj.bias"], sd[a + ".k_proj.bias"], sd[a + ".v_proj.bias"]], 0)
+            lay = dict(
+                ln1=self._ln_pair(sd, p + ".layer_norm"), qkv=self._linear(qkv_w, qkv_b),
+                out=self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"]),
+                ln2=self._ln_pair(sd, p + ".final_layer_norm"),
+                fc1=self._linear(sd[p + ".feed_forward.intermediate_dense.weight"], sd[p + ".feed_forward.intermediate_dense.bias"]),
+                fc2=self._linear(sd[p + ".feed_forward.output_dense.weight"], sd[p + ".feed_forward.output_dense.bias"]))
+            if geo.family == FAMILY_WAVLM:
+                lay["gate_w"] = self._dev_f32(sd[a + ".gru_rel_pos_linear.weight"])
+                lay["gate_b"] = self._dev_f32(sd[a + ".gru_rel_pos_linear.bias"])
+                lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
+            self.layers.append(lay)
+        if geo.family == FAMILY_WAVLM:
+            self.rel_embed = self._dev_f32(sd["encoder.layers.0.attention.rel_attn_embed.weight"])
+
+    # ------------------------------------------------------------------ batch plan
+    def _plan(self, lengths: Sequence[int]):
+        """Row bookkeeping of one ragged batch; cached, so a steady stream of equal-shape
+        batches (the benchmark) re-uses buffers and offset tables."""
+        key = tuple(int(n) for n in lengths)
+        if key in self._cache:
+            return self._cache[key]
+        geo, dev = self.geo, self.device
+        B = len(key)
+        nl = len(geo.conv_dim)
+        chains = [geo.frame_chain(n) for n in key]
+        if min(c[-1] for c in chains) < 1:
+            raise ValueError("utterance shorter than the conv stack's receptive field (400 samples)")
+        pl = dict(B=B, lengths=key)
+        pl["sample_offs"] = torch.tensor(np.concatenate([[0], np.cumsum(key)]), dtype=torch.int64, device=dev)
+        offs = []                               # offs[i][b] = first row of utterance b after conv layer i
+        for i in range(nl):
+            offs.append(np.concatenate([[0], np.cumsum([c[i] for c in chains])]).astype(np.int64))
+        pl["rows"] = [int(o[-1]) for o in offs]
+        pl["frame_offs0"] = torch.tensor(offs[0], dtype=torch.int32, device=dev)
+        C0 = geo.conv_dim[0]
+        rowoffs = []
+        for i in range(1, nl):
+            s = geo.conv_stride[i]
+            ro = np.concatenate([(offs[i - 1][b] + s * np.arange(chains[b][i], dtype=np.int64)) * C0 // 8
+                                 for b in range(B)])
+            rowoffs.append(torch.tensor(ro, dtype=torch.int32, device=dev))
+        pl["conv_rowoff"] = rowoffs
+        T = [c[-1] for c in chains]
+        M = int(offs[-1][-1])
+        pl["T"], pl["M"], pl["Tmax"] = T, M, max(T)
+        pl["frame_offs_host"] = [int(x) for x in offs[-1]]
+        pl["frame_offs"] = torch.tensor(offs[-1], dtype=torch.int32, device=dev)
+        # halo'd layout of the positional-conv input: [64 zero rows][utt 0][64 zero rows][utt 1] ... [64 zero rows]
+        half = geo.pos_conv_kernel // 2
+        starts = np.array([half * (b + 1) + offs[-1][b] for b in range(B)], dtype=np.int64)
+        pl["halo_rows"] = int(M + half * (B + 1))
+        D = geo.hidden
+        pl["halo_rowmap"] = torch.tensor(np.concatenate([starts[b] + np.arange(T[b]) for b in range(B)]),
+                                         dtype=torch.int32, device=dev)
+        pl["pos_rowoff"] = torch.tensor(np.concatenate([(starts[b] - half + np.arange(T[b])) * D // 8 for b in range(B)]),
+                                        dtype=torch.int32, device=dev)
+        # buffers
+        Fd = geo.ffn
+        pl["wave_norm"] = torch.empty(int(sum(key)), dtype=torch.float32, device=dev)
+        pl["conv_act"] = [self._new_act(pl["rows"][0], C0), self._new_act(pl["rows"][1], C0)]   # ping-pong
+        pl["conv_f32"] = torch.empty((pl["rows"][1], C0), dtype=torch.float32, device=dev)
+        pl["feat_f32"] = torch.empty((M, C0), dtype=torch.float32, device=dev)
+        pl["feat_act"] = self._new_act(M, C0)
+        pl["proj_f32"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["halo_act"] = self._new_act(pl["halo_rows"], D, zero=True, extra_rows=1)
+        pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
+        pl["xn"] = self._new_act(M, D)
+        pl["qkv"] = self._new_act(M, 3 * D)
+        pl["ctx"] = self._new_act(M, D)
+        pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["ffn"] = self._new_act(M, Fd)
+        pl["last"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        if geo.family == FAMILY_WAVLM:
+            pl["gate"] = torch.empty((M, geo.heads), dtype=torch.float32, device=dev)
+            pl["table"] = torch.empty((geo.heads, 2 * pl["Tmax"] - 1), dtype=torch.float32, device=dev)
+            check(lib.ser_wavlm_bias_table(self.rel_embed.data_ptr(), pl["table"].data_ptr(), pl["Tmax"], geo.heads,
+                                           geo.num_buckets, geo.max_bucket_distance, _stream()), "ser_wavlm_bias_table")
+        if len(self._cache) >= 4:
+            self._cache.pop(next(iter(self._cache)))
+        self._cache[key] = pl
+        return pl
+
+    # ------------------------------------------------------------------ forward
+    def upload(self, waves: Sequence[np.ndarray]) -> torch.Tensor:
+        """Pack raw fp32 waveforms into one pinned host buffer and copy H2D."""
+        total = int(sum(len(w) for w in waves))
+        host = torch.empty(total, dtype=torch.float32).pin_memory()
+        o = 0
+        for w in waves:
+            n = len(w)
+            host[o:o + n] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+            o += n
+        return host.to(self.device, non_blocking=True)
+
+    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int]) -> HiddenStates:
+        """packed raw samples [sum(lengths)] fp32 on the device -> L+1 hidden states."""
+        geo = self.geo
+        pl = self._plan(lengths)
+        B, M, D, C0 = pl["B"], pl["M"], geo.hidden, geo.conv_dim[0]
+        st = _stream()
+        # a6: zero-mean / unit-variance per utterance
+        check(lib.ser_wave_norm(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), B, pl["wave_norm"].data_ptr(), st),
+              "ser_wave_norm")
+        # a7: conv layer 0 (direct) + LN + GELU
+        a_in = pl["conv_act"][0]
+        check(lib.ser_conv0_ln_gelu(pl["wave_norm"].data_ptr(), pl["sample_offs"].data_ptr(),
+                                    pl["frame_offs0"].data_ptr(), B, self.conv0_w.data_ptr(), _ptr(self.conv0_b),
+                                    self.conv_ln[0][0].data_ptr(), self.conv_ln[0][1].data_ptr(),
+                                    a_in.ptr, a_in.plane_stride, self.mode, C0, geo.conv_kernel[0], geo.conv_stride[0],
+                                    pl["rows"][0], st), "ser_conv0_ln_gelu")
+        # a7: conv layers 1..6 as implicit GEMMs, LN+GELU over channels
+        nl = len(geo.conv_dim)
+        for i in range(1, nl):
+            rows = pl["rows"][i]
+            self._gemm(a_in, self.convs[i - 1], rows, a_rowoff=pl["conv_rowoff"][i - 1],
+                       out_f32=pl["conv_f32"], ldo_f32=C0)
+            if i < nl - 1:
+                a_out = pl["conv_act"][i % 2]
+                a_view = Act.__new__(Act)
+                a_view.t, a_view.rows, a_view.cols, a_view.planes = a_out.t, rows, C0, a_out.planes
+                a_view.plane_stride = a_out.plane_stride
+                self._layernorm(pl["conv_f32"], C0, self.conv_ln[i], rows, C0, gelu=True, out_act=a_view, eps=1e-5)
+                a_in = a_view
+            else:
+                self._layernorm(pl["conv_f32"], C0, self.conv_ln[i], rows, C0, gelu=True, out_f32=pl["feat_f32"], eps=1e-5)
+        # a9: feature projection (LN -> Linear); also scatter into the zero-halo'd pos-conv input
+        self._layernorm(pl["feat_f32"], C0, self.proj_ln, M, C0, out_act=pl["feat_act"])
+        self._gemm(pl["feat_act"], self.proj, M, out_f32=pl["proj_f32"], ldo_f32=D,
+                   out_act=pl["halo_act"], out_rowmap=pl["halo_rowmap"])
+        # a10: grouped positional conv + GELU + residual -> hidden_states[0]
+        states = pl["states"]
+        G, Cg, kc = geo.pos_conv_groups, self.pos_cg, self.pos_kc
+        self._gemm(pl["halo_act"], self.pos, M, a_rowoff=pl["pos_rowoff"], kc=kc, ldj=D, groups=G,
+                   a_group_stride=Cg, w_group_stride=Cg * geo.pos_conv_kernel * kc, c_group_stride=Cg,
+                   N=Cg, K=geo.pos_conv_kernel * kc, act=_lib.ACT_GELU, residual=pl["proj_f32"], ldr=D,
+                   out_f32=states[0], ldo_f32=D)
+        # a11/a12: stable-LayerNorm encoder layers
+        L = geo.num_layers
+        wavlm = geo.family == FAMILY_WAVLM
+        for i, lay in enumerate(self.layers):
+            x = states[i]
+            nxt = states[i + 1] if i + 1 < L else pl["last"]
+            self._layernorm(x, D, lay["ln1"], M, D, out_act=pl["xn"])
+            if wavlm:
+                check(lib.ser_wavlm_gate(pl["xn"].ptr, D, pl["xn"].plane_stride, self.mode, lay["gate_w"].data_ptr(),
+                                         lay["gate_b"].data_ptr(), lay["gate_c"].data_ptr(), pl["gate"].data_ptr(),
+                                         M, geo.heads, geo.head_dim, st), "ser_wavlm_gate")
+            self._gemm(pl["xn"], lay["qkv"], M, out_act=pl["qkv"])
+            if wavlm:
+                self._attention(pl["qkv"], pl["frame_offs"], B, pl["Tmax"], pl["ctx"], table=pl["table"],
+                                table_T=pl["Tmax"], gate=pl["gate"])
+            else:
+                self._attention(pl["qkv"], pl["frame_offs"], B, pl["Tmax"], pl["ctx"])
+            self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D)
+            self._layernorm(pl["h"], D, lay["ln2"], M, D, out_act=pl["xn"])
+            self._gemm(pl["xn"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
+            self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
+        self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
+        return HiddenStates(states, pl["frame_offs_host"])
+
+
+class WhisperEncoder(_EncoderBase):
+    """Whisper encoder (log-mel front end + stem convs + pre-LN layers) on libserhip."""
+
+    N_SAMPLES = 480000
+    N_FRAMES = 3000
+
+    def __init__(self, geo: EncoderGeometry, state_dict, device="cuda:0", mode: str = "bf16", mel_filters=None):
+        super().__init__(geo, device, mode)
+        if geo.family != FAMILY_WHISPER:
+            raise ValueError("WhisperEncoder needs a whisper geometry")
+        sd = state_dict
+        D = geo.hidden
+        from .frontend import whisper_mel_filters
+        self.mel = self._dev_f32(torch.from_numpy(whisper_mel_filters(geo.n_mels) if mel_filters is None else mel_filters))
+        w1 = sd["encoder.conv1.weight"].float()
+        w2 = sd["encoder.conv2.weight"].float()
+        self.conv1 = self._linear(w1.permute(0, 2, 1).reshape(D, -1), sd["encoder.conv1.bias"])
+        self.conv2 = self._linear(w2.permute(0, 2, 1).reshape(D, -1), sd["encoder.conv2.bias"])
+        self.pos_emb = self._dev_f32(sd["encoder.embed_positions.weight"])
+        self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
+        self.layers = []
+        for i in range(geo.num_layers):
+            p = f"encoder.layers.{i}"
+            a = p + ".self_attn"
+            qkv_w = torch.cat([sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]], 0)
+            qkv_b = torch.cat([sd[a + ".q_proj.bias"], torch.zeros(D), sd[a + ".v_proj.bias"]], 0)   # k_proj has no bias
+            self.layers.append(dict(
+                ln1=self._ln_pair(sd, p + ".self_attn_layer_norm"), qkv=self._linear(qkv_w, qkv_b),
+                out=self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"]),
+                ln2=self._ln_pair(sd, p + ".final_layer_norm"),
+                fc1=self._linear(sd[p + ".fc1.weight"], sd[p + ".fc1.bias"]),
+                fc2=self._linear(sd[p + ".fc2.weight"], sd[p + ".fc2.bias"])))
+
+    def _plan(self, lengths):
+        key = tuple(int(n) for n in lengths)
+        if key in self._cache:
+            return self._cache[key]
+        geo, dev = self.geo, self.device
+        B, D, Fd, nm = len(key), geo.hidden, geo.ffn, geo.n_mels
+        T2, T1 = geo.max_source_positions, self.N_FRAMES
+        if T1 != 2 * T2:
+            raise ValueError("max_source_positions must be 1500 (3000 mel frames / 2)")
+        Tp = T1 + 2
+        M = B * T2
+        pl = dict(B=B, M=M, lengths=key)
+        pl["sample_offs"] = torch.tensor(np.concatenate([[0], np.cumsum(key)]), dtype=torch.int64, device=dev)
+        pl["mel"] = torch.empty((B, nm, T1), dtype=torch.float32, device=dev)
+        ws = lib.ser_workspace_bytes(_lib.WS_LOGMEL, B, 0, 0, 0, self.mode)
+        pl["work"] = torch.empty(ws, dtype=torch.uint8, device=dev)
+        pl["mel_act"] = self._new_act(B * Tp, nm)
+        pl["c1_act"] = self._new_act(B * Tp, D, zero=True)
+        b_idx = np.repeat(np.arange(B, dtype=np.int64), T1)
+        t_idx = np.tile(np.arange(T1, dtype=np.int64), B)
+        pl["c1_rowoff"] = torch.tensor((b_idx * Tp + t_idx) * nm // 8, dtype=torch.int32, device=dev)
+        pl["c1_rowmap"] = torch.tensor(b_idx * Tp + 1 + t_idx, dtype=torch.int32, device=dev)
+        b2 = np.repeat(np.arange(B, dtype=np.int64), T2)
+        t2 = np.tile(np.arange(T2, dtype=np.int64), B)
+        pl["c2_rowoff"] = torch.tensor((b2 * Tp + 2 * t2) * D // 8, dtype=torch.int32, device=dev)
+        pl["frame_offs_host"] = [int(b * T2) for b in range(B + 1)]
+        pl["frame_offs"] = torch.tensor(pl["frame_offs_host"], dtype=torch.int32, device=dev)
+        pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
+        pl["xn"] = self._new_act(M, D)
+        pl["qkv"] = self._new_act(M, 3 * D)
+        pl["ctx"] = self._new_act(M, D)
+        pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["ffn"] = self._new_act(M, Fd)
+        pl["last"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        if len(self._cache) >= 2:
+            self._cache.pop(next(iter(self._cache)))
+        self._cache[key] = pl
+        return pl
+
+    upload = SpeechEncoder.upload
+
+    def log_mel(self, packed_wave: torch.Tensor, lengths: Sequence[int]) -> torch.Tensor:
+        """a16: [B, n_mels, 3000] fp32 input_features, computed on the GPU."""
+        pl = self._plan(lengths)
+        check(lib.ser_logmel_whisper(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["B"], self.mel.data_ptr(),
+                                     self.geo.n_mels, pl["mel"].data_ptr(), pl["work"].data_ptr(), _stream()),
+              "ser_logmel_whisper")
+        return pl["mel"]
+
+    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int]) -> HiddenStates:
+        return self.forward_features(self.log_mel(packed_wave, lengths), lengths)
+
+    def forward_features(self, input_features: torch.Tensor, lengths: Sequence[int]) -> HiddenStates:
+        """a17: ``model.encoder(input_features, output_hidden_states=True).hidden_states``."""
+        geo = self.geo
+        pl = self._plan(lengths)
+        B, M, D, nm = pl["B"], pl["M"], geo.hidden, geo.n_mels
+        T1, T2 = self.N_FRAMES, geo.max_source_positions
+        if tuple(input_features.shape) != (B, nm, T1):
+            raise ValueError(f"Whisper expects input_features of shape {(B, nm, T1)}, got {tuple(input_features.shape)}")
+        st = _stream()
+        ma = pl["mel_act"]
+        check(lib.ser_pack_act(input_features.data_ptr(), B, nm, T1, 1, ma.ptr, nm, ma.plane_stride, self.mode, st),
+              "ser_pack_act")
+        # stem: gelu(conv1 k3 p1), gelu(conv2 k3 s2 p1) + embed_positions -> hidden_states[0]
+        self._gemm(ma, self.conv1, B * T1, a_rowoff=pl["c1_rowoff"], act=_lib.ACT_GELU, out_act=pl["c1_act"],
+                   out_rowmap=pl["c1_rowmap"])
+        states = pl["states"]
+        self._gemm(pl["c1_act"], self.conv2, M, a_rowoff=pl["c2_rowoff"], act=_lib.ACT_GELU, residual=self.pos_emb,
+                   ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D)
+        L = geo.num_layers
+        for i, lay in enumerate(self.layers):
+            x = states[i]
+            nxt = states[i + 1] if i + 1 < L else pl["last"]
+            self._layernorm(x, D, lay["ln1"], M, D, out_act=pl["xn"])
+            self._gemm(pl["xn"], lay["qkv"], M, out_act=pl["qkv"])
+            self._attention(pl["qkv"], pl["frame_offs"], B, T2, pl["ctx"])
+            self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D)
+            self._layernorm(pl["h"], D, lay["ln2"], M, D, out_act=pl["xn"])
+            self._gemm(pl["xn"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
+            self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
+        self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
+        return HiddenStates(states, pl["frame_offs_host"])
+
+
+def mean_last4(hs: HiddenStates) -> torch.Tensor:
+    """``--use_average y``: mean of the last four states (preprocess_speech.py:52-63), on the GPU."""
+    s = hs.states
+    out = torch.empty_like(s[0])
+    n = out.numel()
+    check(lib.ser_mean4(s[-4].data_ptr(), s[-3].data_ptr(), s[-2].data_ptr(), s[-1].data_ptr(), out.data_ptr(), n, _stream()),
+          "ser_mean4")
+    return out
+
+
+def build_encoder(geo: EncoderGeometry, state_dict, device="cuda:0", mode="bf16"):
+    if geo.family == FAMILY_WHISPER:
+        return WhisperEncoder(geo, state_dict, device, mode)
+    return SpeechEncoder(geo, state_dict, device, mode)

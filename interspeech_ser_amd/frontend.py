@@ -1,0 +1,106 @@
+"""Host-side front door of the extraction path: audio decode, mel filter bank,
+integer frame arithmetic, feature-file writer.
+
+Mirrors, in this order, the reference's ``librosa.load(path, sr=16000)``
+(preprocess_speech.py:47), the construction of ``WhisperFeatureExtractor.mel_filters``
+(HF feature_extraction_whisper.py:95-103), ``n_frames = ceil(len/320)``
+(preprocess_whisper.py:49-50,75-76) and ``torch.save(feats, <basename>.pt)``
+(preprocess_speech.py:69-71).
+"""
+from __future__ import annotations
+
+import math
+import os
+import wave as _wave
+
+import numpy as np
+import torch
+
+TARGET_SR = 16000
+
+
+class UnsupportedAudio(ValueError):
+    pass
+
+
+def load_wav_16k(path: str) -> np.ndarray:
+    """Decode a RIFF/WAVE file to mono float32 in [-1, 1] the way soundfile (behind
+    ``librosa.load``) does: integer PCM / 2^(bits-1), channels averaged.
+    Only 16 kHz input is accepted: the reference resamples other rates with soxr_hq
+    (librosa 0.10.1), which is not restated here -- such files raise
+    and the driver logs "Failed to process" exactly like any other per-file error."""
+    try:
+        with _wave.open(path, "rb") as wf:
+            sr, ch, width, n = wf.getframerate(), wf.getnchannels(), wf.getsampwidth(), wf.getnframes()
+            raw = wf.readframes(n)
+        if width == 2:
+            x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        elif width == 4:
+            x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+        elif width == 1:
+            x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif width == 3:
+            b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v >= 1 << 23, v - (1 << 24), v)
+            x = (v.astype(np.float64) / 8388608.0).astype(np.float32)
+        else:
+            raise UnsupportedAudio(f"{width * 8}-bit PCM not supported")
+    except _wave.Error:
+        # IEEE-float WAVE files: scipy can read them
+        from scipy.io import wavfile
+        sr, data = wavfile.read(path)
+        if data.dtype.kind != "f":
+            raise
+        x = data.astype(np.float32)
+        ch = 1 if x.ndim == 1 else x.shape[1]
+        x = x.reshape(-1)
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(axis=1).astype(np.float32)
+    if sr != TARGET_SR:
+        raise UnsupportedAudio(f"sample rate {sr} Hz: only {TARGET_SR} Hz input is supported (no resampler)")
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) * (27.0 / np.log(6.4)), 3.0 * f / 200.0)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), 200.0 * m / 3.0)
+
+
+def whisper_mel_filters(n_mels: int = 128, n_fft: int = 400, sr: int = TARGET_SR) -> np.ndarray:
+    """[201, n_mels] slaney-scale, slaney-normalised triangular filters over 0-8 kHz,
+    float64 then cast to fp32 (HF audio_utils.mel_filter_bank as called from
+    feature_extraction_whisper.py:95-103)."""
+    bins = 1 + n_fft // 2
+    freqs = np.linspace(0, sr // 2, bins)
+    pts = _mel_to_hz(np.linspace(_hz_to_mel(0.0), _hz_to_mel(8000.0), n_mels + 2))
+    width = np.diff(pts)
+    slope = pts[None, :] - freqs[:, None]
+    fb = np.maximum(0.0, np.minimum(-slope[:, :-2] / width[:-1], slope[:, 2:] / width[1:]))
+    fb *= (2.0 / (pts[2:] - pts[:-2]))[None, :]
+    return fb.astype(np.float32)
+
+
+def whisper_saved_rows(num_samples: int, feat_dim: int) -> int:
+    """Rows the reference keeps: min(ceil(len/320), feats.shape[1]) where feats is already
+    [1500, D], so the cap is the hidden size (preprocess_whisper.py:49-50,75-76)."""
+    return min(int(math.ceil(num_samples / 320)), int(feat_dim))
+
+
+def feature_path(save_path: str, wav_path: str) -> str:
+    """<save_path>/<splitext(basename(wav))[0]>.pt (preprocess_speech.py:69-70)."""
+    return os.path.join(save_path, os.path.splitext(os.path.basename(wav_path))[0] + ".pt")
+
+
+def save_feature(feats: torch.Tensor, path: str) -> None:
+    """``torch.save`` of a bare [T, D] float32 CPU tensor: what the downstream heads
+    ``torch.load`` (bin/train_cat_bimodal_lazy_1head.py:220-228)."""
+    t = feats.detach()
+    if t.device.type != "cpu":
+        t = t.cpu()
+    torch.save(t.to(torch.float32).contiguous().clone(), path)

@@ -1,0 +1,149 @@
+"""End-to-end parity of the HIP path (through the C ABI) against the committed
+HuggingFace golden states and the CPU oracle.  -m gpu.
+
+Tolerance: max|a-b| <= tol * max(1, max|b|) per hidden state on valid frames;
+tol = 1e-3 for the fp32-grade mode (north_star gate), bf16 mode reports its own (looser) bound.
+Frame counts and layer indexing are compared exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32x": 1e-3, "bf16": 8e-2}
+
+
+def synth_wave(seed, n):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    x = 0.1 * rng.standard_normal(n) + 0.2 * np.sin(2 * np.pi * 220.0 * t)
+    return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+def rel_err(got, ref):
+    return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+def _speech_cases():
+    from interspeech_ser_amd import config as C
+    return [("tiny_wavlm_d128h2", C.TINY_WAVLM), ("tiny_wav2vec2_d960h8", C.TINY_WAV2VEC2),
+            ("tiny_hubert_d320h4", C.TINY_HUBERT)]
+
+
+@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_speech_golden_ragged_batch(golden_dir, mode, case):
+    """Both fixture utterances in ONE ragged batch must reproduce the per-utterance HF states."""
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict, state_dict_digest
+    tag, geo = _speech_cases()[case]
+    gold = np.load(os.path.join(golden_dir, tag + ".npz"))
+    sd = synthetic_state_dict(geo, int(gold["seed"]))
+    assert state_dict_digest(sd) == str(gold["digest"]), "RNG stream drifted: fixture weights not reproducible"
+    lengths = [int(n) for n in gold["lengths"]]
+    waves = [synth_wave(int(gold[f"wave_seed_{j}"]), n) for j, n in enumerate(lengths)]
+    enc = SpeechEncoder(geo, sd, "cuda:0", mode=mode)
+    hs = enc.forward(enc.upload(waves), lengths)
+    torch.cuda.synchronize()
+    assert len(hs) == geo.num_layers + 1
+    worst = 0.0
+    for j, n in enumerate(lengths):
+        ref = torch.from_numpy(gold[f"states_{j}"])                       # [L+1, T, D]
+        assert hs.frames(j) == ref.shape[1] == geo.frames_for(n)          # bit-exact frame count
+        for layer in range(ref.shape[0]):
+            worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
+    print(f"{tag} {mode}: worst rel err {worst:.3e}")
+    assert worst < TOL[mode], worst
+
+
+def test_batched_equals_single(golden_dir):
+    """Packed ragged batch == batch-of-one runs (the reference's B=1 loop), to fp32 rounding."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_WAVLM
+    sd = synthetic_state_dict(geo, 11)
+    lengths = [4000, 16000, 401 + 320 * 3, 9000]
+    waves = [synth_wave(50 + i, n) for i, n in enumerate(lengths)]
+    enc = SpeechEncoder(geo, sd, "cuda:0", mode="fp32x")
+    hs = enc.forward(enc.upload(waves), lengths)
+    batched = [[hs.utterance(b, l).cpu().clone() for l in range(len(hs))] for b in range(len(waves))]
+    for b, w in enumerate(waves):
+        one = enc.forward(enc.upload([w]), [len(w)])
+        for l in range(len(one)):
+            assert torch.equal(one.utterance(0, l).cpu(), batched[b][l]), (b, l)
+
+
+@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+def test_whisper_golden(golden_dir, mode):
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import WhisperEncoder
+    from interspeech_ser_amd.frontend import whisper_saved_rows
+    from interspeech_ser_amd.weights import synthetic_state_dict, state_dict_digest
+    geo = C.TINY_WHISPER
+    gold = np.load(os.path.join(golden_dir, "tiny_whisper_d128h2.npz"))
+    sd = synthetic_state_dict(geo, int(gold["seed"]))
+    assert state_dict_digest(sd) == str(gold["digest"])
+    lengths = [int(n) for n in gold["lengths"]]
+    waves = [synth_wave(int(gold[f"wave_seed_{j}"]), n) for j, n in enumerate(lengths)]
+    enc = WhisperEncoder(geo, sd, "cuda:0", mode=mode)
+    packed = enc.upload(waves)
+    mel = enc.log_mel(packed, lengths).cpu().numpy()
+    hs = enc.forward(packed, lengths)
+    torch.cuda.synchronize()
+    assert len(hs) == geo.num_layers + 1
+    worst = 0.0
+    for j, n in enumerate(lengths):
+        assert np.abs(mel[j][:, ::50] - gold[f"mel_probe_{j}"]).max() < 1e-3
+        rows = whisper_saved_rows(n, geo.hidden)
+        assert rows == int(gold[f"rows_{j}"])                              # integer crop gate
+        ref = torch.from_numpy(gold[f"states_{j}"])
+        for layer in range(ref.shape[0]):
+            worst = max(worst, rel_err(hs.utterance(j, layer)[:rows].cpu(), ref[layer]))
+    print(f"whisper {mode}: worst rel err {worst:.3e}")
+    assert worst < TOL[mode], worst
+
+
+def test_mean_last4_matches_reference_rule():
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder, mean_last4
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.tiny_geometry(C.FAMILY_WAVLM, layers=4)
+    sd = synthetic_state_dict(geo, 3)
+    w = synth_wave(1, 8000)
+    enc = SpeechEncoder(geo, sd, "cuda:0", mode="fp32x")
+    hs = enc.forward(enc.upload([w]), [len(w)])
+    got = mean_last4(hs).cpu()
+    ref = O.extract_speech(geo, sd, w, use_average=True)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-3
+
+
+def test_full_size_wavlm_large_pins(golden_dir):
+    """WavLM-large geometry, seed-0 weights, one 3 s clip: probe values and per-state scalars recorded
+    from HuggingFace in the build container (BASELINE configs[0] shape: [149, 1024])."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict, state_dict_digest
+    gold = np.load(os.path.join(golden_dir, "wavlm_large_pins.npz"))
+    geo = C.WAVLM_LARGE
+    sd = synthetic_state_dict(geo, 0)
+    assert state_dict_digest(sd) == str(gold["digest"])
+    w = synth_wave(int(gold["wave_seed"]), int(gold["num_samples"]))
+    enc = SpeechEncoder(geo, sd, "cuda:0", mode="fp32x")
+    hs = enc.forward(enc.upload([w]), [len(w)])
+    torch.cuda.synchronize()
+    nstates, T, D = (int(x) for x in gold["shape"])
+    assert (len(hs), hs.frames(0), hs.states.shape[2]) == (nstates, T, D) == (25, 149, 1024)
+    pr, pc = gold["probe_rows"], gold["probe_cols"]
+    worst = 0.0
+    for layer in range(nstates):
+        st = hs.utterance(0, layer).cpu()
+        scale = max(1.0, float(gold["absmax"][layer]))
+        worst = max(worst, float(np.abs(st.numpy()[pr, pc] - gold["probes"][layer]).max()) / scale)
+        assert abs(float(st.norm()) - float(gold["l2"][layer])) / float(gold["l2"][layer]) < 1e-3
+    print(f"wavlm-large fp32x probes: worst rel err {worst:.3e}")
+    assert worst < 1e-3, worst

@@ -1,0 +1,409 @@
+"""Kernel-level parity tests: every libserhip entry point against a plain fp32/fp64
+PyTorch-CPU statement of the same op, called through the C ABI (ctypes).  -m gpu."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from interspeech_ser_amd import _lib
+    assert torch.cuda.is_available()
+    return _lib
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def to_act(x, mode):
+    """fp32 CPU [rows, cols] -> device bf16 planes the way ser_split_bf16 does (host restatement)."""
+    hi = x.to(torch.bfloat16)
+    if mode == 1:
+        return hi[None].contiguous().to(DEV)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).contiguous().to(DEV)
+
+
+def act_value(t):
+    return t.float().sum(0)
+
+
+def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
+    g = L.GemmArgs()
+    g.A = A_act.data_ptr() + kw.get("a_byte_offset", 0)
+    g.a_plane_stride = A_act.shape[1] * A_act.shape[2]
+    g.a_rowoff = kw["a_rowoff"].data_ptr() if kw.get("a_rowoff") is not None else None
+    g.lda = kw.get("lda", A_act.shape[2])
+    g.kc, g.ldj = kw.get("kc", 0), kw.get("ldj", 0)
+    g.W = W_act.data_ptr()
+    g.w_plane_stride = W_act.shape[1] * W_act.shape[2]
+    g.M, g.N, g.K = M, N, K
+    g.groups = kw.get("groups", 1)
+    g.a_group_stride, g.w_group_stride, g.c_group_stride = kw.get("ags", 0), kw.get("wgs", 0), kw.get("cgs", 0)
+    g.mode = mode
+    bias = kw.get("bias")
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.act = kw.get("act", 0)
+    res = kw.get("residual")
+    g.residual = res.data_ptr() if res is not None else None
+    g.ldr = kw.get("ldr", 0)
+    g.res_row_mod = kw.get("res_row_mod", 0)
+    ncols = kw.get("out_cols", N * g.groups)
+    out_f32 = torch.full((kw.get("out_rows", M), ncols), float("nan"), device=DEV) if kw.get("want_f32", True) else None
+    g.out_f32 = out_f32.data_ptr() if out_f32 is not None else None
+    g.ldo_f32 = ncols
+    planes = 2 if mode == 2 else 1
+    out_act = None
+    if kw.get("want_act", False):
+        out_act = torch.zeros((planes, kw.get("out_act_rows", M), ncols), dtype=torch.bfloat16, device=DEV)
+        g.out_act = out_act.data_ptr()
+        g.ldo_act = ncols
+        g.out_plane_stride = out_act.shape[1] * ncols
+    rm = kw.get("out_rowmap")
+    g.out_rowmap = rm.data_ptr() if rm is not None else None
+    L.check(L.lib.ser_gemm(C.byref(g), stream()), "ser_gemm")
+    torch.cuda.synchronize()
+    return out_f32, out_act
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (77, 8, 64), (515, 392, 1024)])
+def test_gemm_integer_exact(L, mode, M, N, K):
+    """Small-integer operands are exact in bf16 and fp32: any layout / swizzle / permutation slip
+    shows up as a wrong integer.  W is asymmetric on purpose."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()
+    ref = A.double() @ W.double().T
+    out, _ = run_gemm(L, to_act(A, mode), to_act(W, mode), M, N, K, mode)
+    assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 2e-5)])
+def test_gemm_epilogue_and_precision(L, mode, tol):
+    M, N, K = 391, 264, 512
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.gelu(A.double() @ W.double().T + bias.double()) + res.double()
+    out, oact = run_gemm(L, to_act(A, mode), to_act(W, mode), M, N, K, mode, bias=bias.to(DEV), act=1,
+                         residual=res.to(DEV), ldr=N, want_act=True)
+    err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+    # the act output is the same value, re-split
+    err_act = (act_value(oact).cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err_act < (1e-2 if mode == 1 else 5e-5), err_act
+
+
+def test_gemm_fp32x_beats_bf16(L):
+    M, N, K = 256, 256, 2048
+    g = torch.Generator().manual_seed(5)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    ref = A.double() @ W.double().T
+    e = {}
+    for mode in (1, 2):
+        out, _ = run_gemm(L, to_act(A, mode), to_act(W, mode), M, N, K, mode)
+        e[mode] = ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert e[2] < 2e-5 and e[2] * 50 < e[1], e
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gemm_conv_rowmap(L, mode):
+    """Strided Conv1d (k=3, stride 2) over channels-last rows of two packed utterances."""
+    Cin, Cout, k, s = 64, 72, 3, 2
+    T_in = [41, 30]
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(-2, 3, (sum(T_in), Cin), generator=g).float()
+    w = torch.randint(-2, 3, (Cout, Cin, k), generator=g).float()
+    T_out = [(t - k) // s + 1 for t in T_in]
+    offs_in = np.concatenate([[0], np.cumsum(T_in)])
+    ro = np.concatenate([(offs_in[b] + s * np.arange(T_out[b])) * Cin // 8 for b in range(2)])
+    ref = []
+    for b in range(2):
+        xb = x[offs_in[b]:offs_in[b + 1]].T[None]
+        ref.append(torch.nn.functional.conv1d(xb, w, stride=s)[0].T)
+    ref = torch.cat(ref)
+    W2 = w.permute(0, 2, 1).reshape(Cout, k * Cin)
+    out, _ = run_gemm(L, to_act(x, mode), to_act(W2, mode), sum(T_out), Cout, k * Cin, mode,
+                      a_rowoff=torch.tensor(ro, dtype=torch.int32, device=DEV))
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("Cg", [64, 80, 120])
+def test_gemm_grouped_posconv(L, mode, Cg):
+    """Grouped conv (k=128, pad 64, drop last frame) through the kc/ldj map with channel padding
+    to 64 and a zero-halo'd input, + GELU + residual."""
+    G, k = 2, 128
+    D = G * Cg
+    kc = ((Cg + 63) // 64) * 64
+    T = [37, 20]
+    half = k // 2
+    g = torch.Generator().manual_seed(Cg)
+    x = torch.randn(sum(T), D, generator=g)
+    x = x.to(torch.bfloat16).float() if mode == 1 else x
+    w = torch.randn(D, Cg, k, generator=g) / math.sqrt(Cg * k)
+    w = w.to(torch.bfloat16).float() if mode == 1 else w
+    bias = torch.randn(D, generator=g)
+    offs = np.concatenate([[0], np.cumsum(T)])
+    starts = [half * (b + 1) + offs[b] for b in range(2)]
+    halo_rows = sum(T) + half * 3
+    xh = torch.zeros(halo_rows + 1, D)
+    for b in range(2):
+        xh[starts[b]:starts[b] + T[b]] = x[offs[b]:offs[b + 1]]
+    ro = np.concatenate([(starts[b] - half + np.arange(T[b])) * D // 8 for b in range(2)])
+    wp = torch.zeros(G, Cg, k, kc)
+    wp[..., :Cg] = w.view(G, Cg, Cg, k).permute(0, 1, 3, 2)
+    ref = []
+    for b in range(2):
+        xb = x[offs[b]:offs[b + 1]].T[None].double()
+        y = torch.nn.functional.conv1d(xb, w.double(), bias.double(), padding=half, groups=G)[:, :, :-1]
+        ref.append(torch.nn.functional.gelu(y)[0].T + x[offs[b]:offs[b + 1]].double())
+    ref = torch.cat(ref)
+    out, _ = run_gemm(L, to_act(xh, mode), to_act(wp.reshape(G * Cg, k * kc), mode), sum(T), Cg, k * kc, mode,
+                      a_rowoff=torch.tensor(ro, dtype=torch.int32, device=DEV), kc=kc, ldj=D, groups=G, ags=Cg,
+                      wgs=Cg * k * kc, cgs=Cg, bias=bias.to(DEV), act=1, residual=x.to(DEV), ldr=D)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < (2e-3 if mode == 1 else 3e-5), err
+
+
+def test_gemm_rowmap_and_rowmod(L):
+    M, N, K, mod = 90, 64, 64, 30
+    g = torch.Generator().manual_seed(2)
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    W = torch.randint(-2, 3, (N, K), generator=g).float()
+    pos = torch.randint(-5, 6, (mod, N), generator=g).float()
+    rowmap = torch.tensor(np.arange(M) * 2 + 1, dtype=torch.int32, device=DEV)
+    out, oact = run_gemm(L, to_act(A, 1), to_act(W, 1), M, N, K, 1, residual=pos.to(DEV), ldr=N, res_row_mod=mod,
+                         want_act=True, out_act_rows=2 * M + 1, out_rowmap=rowmap)
+    ref = A @ W.T + pos.repeat(M // mod, 1)
+    assert torch.equal(out.cpu(), ref)
+    got = act_value(oact).cpu()
+    assert torch.equal(got[1::2][:M], ref.to(torch.bfloat16).float())
+    assert torch.count_nonzero(got[0::2]) == 0
+
+
+def test_gemm_rejects_bad_shapes(L):
+    g = L.GemmArgs()
+    assert L.lib.ser_gemm(C.byref(g), None) < 0
+    assert b"null" in L.lib.ser_last_error()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("D,gelu", [(512, True), (1024, False), (1920, False), (64, True)])
+def test_layernorm(L, mode, D, gelu):
+    rows = 37
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(rows, D, generator=g) * 3 + 0.5
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5)
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    of = torch.empty(rows, D, device=DEV)
+    planes = 2 if mode == 2 else 1
+    oa = torch.empty(planes, rows, D, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib.ser_layernorm(xd.data_ptr(), D, wd.data_ptr(), bd.data_ptr(), 1e-5, int(gelu), of.data_ptr(), D,
+                                oa.data_ptr(), D, rows * D, mode, rows, D, stream()))
+    torch.cuda.synchronize()
+    assert (of.cpu().double() - ref).abs().max().item() < 2e-5
+    assert (act_value(oa).cpu().double() - ref).abs().max().item() < (4e-2 if mode == 1 else 1e-4)
+
+
+def test_wave_norm(L):
+    lens = [16000, 401, 23457]
+    g = np.random.default_rng(0)
+    waves = [(0.1 * g.standard_normal(n) + 0.03).astype(np.float32) for n in lens]
+    packed = torch.from_numpy(np.concatenate(waves)).to(DEV)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=DEV)
+    out = torch.empty_like(packed)
+    L.check(L.lib.ser_wave_norm(packed.data_ptr(), offs.data_ptr(), len(lens), out.data_ptr(), stream()))
+    got = out.cpu().numpy()
+    o = 0
+    for w in waves:
+        ref = (w - w.mean()) / np.sqrt(w.var() + 1e-7)          # HF zero_mean_unit_var_norm
+        assert np.abs(got[o:o + len(w)] - ref).max() < 2e-5
+        o += len(w)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("Cc,bias", [(64, True), (512, False)])
+def test_conv0_ln_gelu(L, mode, Cc, bias):
+    lens = [2000, 1205]
+    k, s = 10, 5
+    g = torch.Generator().manual_seed(Cc)
+    x = [torch.randn(n, generator=g) for n in lens]
+    w = torch.randn(Cc, 1, k, generator=g) * 0.5
+    bvec = torch.randn(Cc, generator=g) if bias else None
+    lw, lb = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    T = [(n - k) // s + 1 for n in lens]
+    ref = []
+    for xb in x:
+        y = torch.nn.functional.conv1d(xb[None, None].double(), w.double(), None if bvec is None else bvec.double(), stride=s)
+        y = torch.nn.functional.layer_norm(y[0].T, (Cc,), lw.double(), lb.double(), 1e-5)
+        ref.append(torch.nn.functional.gelu(y))
+    ref = torch.cat(ref)
+    packed = torch.cat(x).to(DEV)
+    soffs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=DEV)
+    foffs = torch.tensor(np.concatenate([[0], np.cumsum(T)]), dtype=torch.int32, device=DEV)
+    planes = 2 if mode == 2 else 1
+    out = torch.empty(planes, sum(T), Cc, dtype=torch.bfloat16, device=DEV)
+    wd = w.reshape(Cc, k).contiguous().to(DEV)
+    bd = bvec.to(DEV) if bias else None
+    lwd, lbd = lw.to(DEV), lb.to(DEV)
+    L.check(L.lib.ser_conv0_ln_gelu(packed.data_ptr(), soffs.data_ptr(), foffs.data_ptr(), 2, wd.data_ptr(),
+                                    bd.data_ptr() if bias else None, lwd.data_ptr(), lbd.data_ptr(), out.data_ptr(),
+                                    sum(T) * Cc, mode, Cc, k, s, sum(T), stream()))
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < (4e-2 if mode == 1 else 2e-4), err
+
+
+def test_bias_table_bit_exact(L, golden_dir):
+    """Bucket function against the committed HF table for rel in [-1500, 1500] (integer gate)."""
+    gold = np.load(os.path.join(golden_dir, "integer_tables.npz"))
+    T, H, NB = 1501, 4, 320
+    emb = (torch.arange(NB)[:, None] * 10 + torch.arange(H)[None, :]).float()      # value encodes (bucket, head)
+    table = torch.empty(H, 2 * T - 1, device=DEV)
+    embd = emb.to(DEV)
+    L.check(L.lib.ser_wavlm_bias_table(embd.data_ptr(), table.data_ptr(), T, H, NB, 800, stream()))
+    got = table.cpu()
+    buckets = torch.from_numpy(gold["buckets"].astype(np.int64))                     # rel = -1500..1500
+    for h in range(H):
+        assert torch.equal(got[h], buckets.float() * 10 + h)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_wavlm_gate(L, mode):
+    rows, H, dh = 53, 4, 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(rows, H * dh, generator=g)
+    w8, b8, cst = torch.randn(8, dh, generator=g) * 0.3, torch.randn(8, generator=g) * 0.3, torch.randn(H, generator=g)
+    xa = to_act(x, mode)
+    xv = act_value(xa).cpu().double()
+    p = torch.nn.functional.linear(xv.view(rows, H, dh), w8.double(), b8.double()).view(rows, H, 2, 4).sum(-1)
+    a, b = torch.sigmoid(p).unbind(-1)
+    ref = a * (b * cst.double()[None, :] - 1.0) + 2.0
+    gate = torch.empty(rows, H, device=DEV)
+    w8d, b8d, cd = w8.to(DEV), b8.to(DEV), cst.to(DEV)
+    L.check(L.lib.ser_wavlm_gate(xa.data_ptr(), H * dh, rows * H * dh, mode, w8d.data_ptr(), b8d.data_ptr(),
+                                 cd.data_ptr(), gate.data_ptr(), rows, H, dh, stream()))
+    assert (gate.cpu().double() - ref).abs().max().item() < 1e-5
+
+
+def attention_reference(q, k, v, scale, table=None, gate=None):
+    """fp64 statement of softmax(q k^T scale + gate*bias) v for one utterance, [H, T, dh] inputs."""
+    T = q.shape[1]
+    s = torch.matmul(q, k.transpose(1, 2)) * scale
+    if table is not None:
+        idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None]) + (table.shape[1] - 1) // 2
+        s = s + gate.T[:, :, None] * table[:, idx]
+    return torch.matmul(torch.softmax(s, dim=-1), v)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dh,H,bias", [(64, 2, True), (64, 3, False), (80, 2, False), (120, 2, False), (128, 1, False)])
+def test_attention(L, mode, dh, H, bias):
+    Ts = [70, 129, 5, 200]
+    D = H * dh
+    M = sum(Ts)
+    g = torch.Generator().manual_seed(dh + H)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    qkv[:, : 2 * D] *= 1.5
+    qa = to_act(qkv, mode)
+    qv = act_value(qa).cpu().double()
+    Tmax = max(Ts)
+    table = gate = None
+    if bias:
+        table = torch.randn(H, 2 * Tmax - 1, generator=g)
+        gate = torch.rand(M, H, generator=g) * 2
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    ref = torch.empty(M, D, dtype=torch.float64)
+    for b, T in enumerate(Ts):
+        blk = qv[offs[b]:offs[b + 1]]
+        q, k, v = (blk[:, i * D:(i + 1) * D].view(T, H, dh).permute(1, 0, 2) for i in range(3))
+        tb = gt = None
+        if bias:
+            c = Tmax - 1
+            tb = table[:, c - (T - 1): c + T].double()
+            gt = gate[offs[b]:offs[b + 1]].double()
+        o = attention_reference(q, k, v, dh ** -0.5, tb, gt)
+        ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
+    planes = 2 if mode == 2 else 1
+    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    td = table.to(DEV) if bias else None
+    gd = gate.to(DEV) if bias else None
+    L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
+                                td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
+                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, stream()))
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < (3e-2 if mode == 1 else 1e-4), err
+
+
+def test_attention_online_softmax_rescale(L):
+    """A key in a late tile dominates: forces the running-max rescale branch (one spike per head)."""
+    T, H, dh = 300, 1, 64
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(T, 3 * dh, generator=g) * 0.5
+    qkv[250, dh:2 * dh] = qkv[10, :dh] * 30           # key 250 aligned with query 10
+    qa = to_act(qkv, 2)
+    qv = act_value(qa).cpu().double()
+    q, k, v = (qv[:, i * dh:(i + 1) * dh].view(T, 1, dh).permute(1, 0, 2) for i in range(3))
+    ref = attention_reference(q, k, v, dh ** -0.5)[0]
+    out = torch.zeros(2, T, dh, dtype=torch.bfloat16, device=DEV)
+    foffs = torch.tensor([0, T], dtype=torch.int32, device=DEV)
+    L.check(L.lib.ser_attention(qa.data_ptr(), 3 * dh, T * 3 * dh, 0, dh, 2 * dh, foffs.data_ptr(), 1, T, None, 0, None,
+                                out.data_ptr(), dh, T * dh, H, dh, dh ** -0.5, 2, stream()))
+    torch.cuda.synchronize()
+    assert (act_value(out).cpu().double() - ref).abs().max().item() < 1e-4
+
+
+def test_mean4_and_split(L):
+    n = 1000
+    g = torch.Generator().manual_seed(4)
+    s = [torch.randn(n, generator=g) for _ in range(4)]
+    d = [t.to(DEV) for t in s]
+    out = torch.empty(n, device=DEV)
+    L.check(L.lib.ser_mean4(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), out.data_ptr(), n, stream()))
+    assert torch.equal(out.cpu(), torch.stack(s).mean(0)) or (out.cpu() - torch.stack(s).mean(0)).abs().max() < 1e-7
+    x = torch.randn(777, generator=g)
+    xo = torch.empty(2, 777, dtype=torch.bfloat16, device=DEV)
+    xd = x.to(DEV)
+    L.check(L.lib.ser_split_bf16(xd.data_ptr(), xo.data_ptr(), 777, 2, 777, stream()))
+    ref = to_act(x[None], 2)[:, 0]
+    assert torch.equal(xo.cpu(), ref.cpu())
+
+
+def test_logmel_whisper(L, golden_dir):
+    from interspeech_ser_amd.frontend import whisper_mel_filters
+    from oracle import ssl_oracle as O
+    lens = [16000, 100000, 500000]
+    rng = np.random.default_rng(3)
+    waves = [np.clip(0.1 * rng.standard_normal(n) + 0.2 * np.sin(2 * np.pi * 220 * np.arange(n) / 16000), -1, 1).astype(np.float32)
+             for n in lens]
+    packed = torch.from_numpy(np.concatenate(waves)).to(DEV)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=DEV)
+    mel = torch.from_numpy(whisper_mel_filters(128)).to(DEV)
+    B = len(lens)
+    out = torch.empty(B, 128, 3000, device=DEV)
+    ws = L.lib.ser_workspace_bytes(L.WS_LOGMEL, B, 0, 0, 0, 1)
+    work = torch.empty(ws, dtype=torch.uint8, device=DEV)
+    L.check(L.lib.ser_logmel_whisper(packed.data_ptr(), offs.data_ptr(), B, mel.data_ptr(), 128, out.data_ptr(),
+                                     work.data_ptr(), stream()))
+    got = out.cpu().numpy()
+    for b, w in enumerate(waves):
+        ref = O.whisper_log_mel(w, 128)
+        assert np.abs(got[b] - ref).max() < 1e-3, np.abs(got[b] - ref).max()
