@@ -18,6 +18,7 @@ import math
 import os
 from typing import Dict
 
+import numpy as np
 import torch
 
 from .config import EncoderGeometry, FAMILY_WAVLM, FAMILY_WHISPER
@@ -26,12 +27,15 @@ StateDict = Dict[str, torch.Tensor]
 
 
 class _Rng:
+    """numpy PCG64 stream: unlike torch's CPU ``randn`` (whose vectorised fill depends on the
+    host's SIMD width) it yields the same numbers in the build container and on the GPU box."""
+
     def __init__(self, seed: int):
-        self.g = torch.Generator(device="cpu")
-        self.g.manual_seed(int(seed))
+        self.g = np.random.default_rng(int(seed))
 
     def normal(self, *shape, std=1.0, mean=0.0):
-        return torch.randn(*shape, generator=self.g, dtype=torch.float32) * std + mean
+        x = self.g.standard_normal(size=shape, dtype=np.float32)
+        return torch.from_numpy(x) * std + mean
 
 
 def _linear(sd, r, name, out_f, in_f, gain=0.7, bias=True):
@@ -48,9 +52,10 @@ def _layer_norm(sd, r, name, dim):
 def whisper_sinusoids(length: int, channels: int) -> torch.Tensor:
     """Whisper's frozen position table at init (HF modeling_whisper.py:55-64)."""
     inc = math.log(10000.0) / (channels // 2 - 1)
-    inv = torch.exp(-inc * torch.arange(channels // 2, dtype=torch.float32))
-    t = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
-    return torch.cat([t.sin(), t.cos()], dim=1)
+    inv = np.exp(-inc * np.arange(channels // 2, dtype=np.float64))
+    t = np.arange(length, dtype=np.float64)[:, None] * inv[None, :]
+    # float64 then one rounding: bit-identical on every host (fixture digests depend on it)
+    return torch.from_numpy(np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32))
 
 
 def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
@@ -90,7 +95,8 @@ def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
 
     cg = D // geo.pos_conv_groups
     v = r.normal(D, cg, geo.pos_conv_kernel, std=math.sqrt(2.0 / (cg * geo.pos_conv_kernel)))
-    g = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt() * r.normal(1, 1, geo.pos_conv_kernel, std=0.1, mean=1.0)
+    vnorm = np.sqrt((v.numpy().astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True)).astype(np.float32)
+    g = torch.from_numpy(vnorm) * r.normal(1, 1, geo.pos_conv_kernel, std=0.1, mean=1.0)
     sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = g
     sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = v
     sd["encoder.pos_conv_embed.conv.bias"] = r.normal(D, std=0.05)
