@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Headline benchmark: utterances/s of WavLM-large embedding extraction (10 s @ 16 kHz).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (waveform normalisation -> conv stack -> projection ->
+positional conv -> 24 encoder layers -> final LayerNorm, all L+1 hidden states written to HBM)
+over one batch of 16 synthetic 10 s clips already resident in HBM (BASELINE.json configs[1]).
+Utterances shard across ranks with no data-path collective (weak scaling): the only RCCL
+traffic is the one-time broadcast of the frozen weights from rank 0.
+
+One JSON line on rank 0: metric/value/unit + `roofline` (dominant kernel = the MFMA GEMM,
+live HIP-event timing inside the timed region) + `cpu_baseline` (CPU oracle, reference-style
+batch-of-one driver, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def algorithmic_gflop_per_utt(geo, num_samples):
+    """2*MAC over valid frames only (384.0 for WavLM-large @ 10 s)."""
+    chain = geo.frame_chain(num_samples)
+    cin, fl = 1, 0.0
+    for t, c, k in zip(chain, geo.conv_dim, geo.conv_kernel):
+        fl += 2.0 * t * c * cin * k
+        cin = c
+    T, D, F, H = chain[-1], geo.hidden, geo.ffn, geo.heads
+    fl += 2.0 * T * cin * D
+    fl += 2.0 * T * D * (D // geo.pos_conv_groups) * geo.pos_conv_kernel
+    per_layer = 2.0 * T * D * 3 * D + 2.0 * T * D * D + 2 * (2.0 * T * T * D) + 2 * (2.0 * T * D * F)
+    return (fl + geo.num_layers * per_layer) / 1e9
+
+
+def synth_batch(batch, num_samples, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(0.1 * torch.randn(num_samples, generator=g)).numpy() for _ in range(batch)]
+
+
+def broadcast_weights(geo, seed, rank, world, device):
+    """C1: rank 0 owns the frozen weights; everyone else receives them over RCCL/xGMI in one
+    flat fp32 bucket.  With world == 1 this is just the synthetic init."""
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    import torch.distributed as dist
+    sd = synthetic_state_dict(geo, seed if rank == 0 else seed + 1 + rank)   # non-root values are overwritten
+    if world == 1:
+        return sd, 0.0
+    names = sorted(sd)
+    flat = torch.cat([sd[n].reshape(-1) for n in names]).to(device)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(flat, src=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flat = flat.cpu()
+    o = 0
+    for n in names:
+        k = sd[n].numel()
+        sd[n] = flat[o:o + k].view_as(sd[n]).clone()
+        o += k
+    return sd, dt
+
+
+def cpu_baseline(geo, sd, num_samples, n_clips=6):
+    """The CPU oracle driven like the reference: batch of one, ThreadPoolExecutor(4)
+    (preprocess_speech.py:120-122), default torch intra-op threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import ssl_oracle as O
+    clips = synth_batch(n_clips + 1, num_samples, 4321)
+
+    def one(w):
+        with torch.no_grad():
+            return O.speech_hidden_states(geo, sd, torch.from_numpy(O.zero_mean_unit_var(w)))[-1].shape
+
+    one(clips[0])                                    # warm-up
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(one, clips[1:]))
+    dt = time.perf_counter() - t0
+    return {"value": round(n_clips / dt, 4), "unit": "utterances/s", "cores": int(torch.get_num_threads()),
+            "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": f"{n_clips} x {num_samples / 16000:.0f} s clips, batch of 1, 4-thread driver, fp32 PyTorch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--ssl_type", type=str, default="microsoft/wavlm-large")
+    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x"])
+    ap.add_argument("--layers", type=int, default=0, help="debug: truncate the encoder (invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="skip per-launch GEMM events")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import build_encoder
+    geo = C.geometry_for(args.ssl_type)
+    if args.layers:
+        geo = C.with_layers(geo, args.layers)
+    if geo.family == C.FAMILY_WHISPER:
+        raise SystemExit("bench.py measures the speech families; see DESIGN.md for the Whisper figures")
+    num_samples = int(round(args.seconds * 16000))
+
+    sd, bcast_s = broadcast_weights(geo, 0, rank, world, device)
+    enc = build_encoder(geo, sd, device, args.mode)
+    waves = synth_batch(args.batch, num_samples, 1234 + rank)
+    lengths = [num_samples] * args.batch
+    packed = enc.upload(waves)
+    torch.cuda.synchronize()
+
+    if args.no_graph:
+        step = lambda: enc.forward(packed, lengths)
+    else:
+        graph, hs = enc.capture(packed, lengths)
+        step = graph.replay
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    # Roofline leg: the same K steps again, launched eagerly with a HIP event pair around every
+    # ser_gemm launch on the launch stream (events cannot be timed inside a replayed graph).
+    trace = None
+    if not args.no_trace:
+        enc.gemm_trace = []
+        for _ in range(args.steps):
+            enc.forward(packed, lengths)
+        torch.cuda.synchronize()
+        trace, enc.gemm_trace = enc.gemm_trace, None
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        total_utts = args.batch * args.steps * world
+        value = total_utts / elapsed
+        gf_utt = algorithmic_gflop_per_utt(geo, num_samples)
+        out = {
+            "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract",
+            "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.mode == "bf16" else "bf16x3 (fp32-grade split)", "data": "synthetic",
+            "config": {"workload": f"{geo.name} embed extract, batch={args.batch} x {args.seconds:.0f} s @16 kHz per GPU, "
+                                   f"all {geo.num_layers + 1} hidden states to HBM, mode={args.mode}",
+                       "frames_per_utt": geo.frames_for(num_samples), "gflop_per_utt": round(gf_utt, 1),
+                       "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
+            "achieved_tflops_whole_path": round(value * gf_utt / 1e3 / world, 1),
+            "launch": "eager" if args.no_graph else "hipGraph replay",
+            "weight_broadcast_s": round(bcast_s, 4),
+        }
+        if trace:
+            dur_ms = sum(a.elapsed_time(b) for a, b, _ in trace)
+            flops = sum(f for _, _, f in trace)
+            n = len(trace)
+            achieved = flops / (dur_ms * 1e-3) / 1e12
+            mult = 3.0 if args.mode == "fp32x" else 1.0
+            out["roofline"] = {
+                "kernel": "ser_gemm_kernel (bf16 MFMA implicit-conv GEMM + fused epilogue)",
+                "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": n, "avg_launch_us": round(1e3 * dur_ms / n, 2),
+                "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
+                "mfma_products_per_algorithmic_flop": mult,
+                "gemm_ms_per_step": round(dur_ms / args.steps, 3),
+                "measured": "HIP events around every ser_gemm launch, eager pass of the same K steps right after the timed region",
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            from interspeech_ser_amd.weights import synthetic_state_dict
+            out["cpu_baseline"] = cpu_baseline(geo, sd, num_samples)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

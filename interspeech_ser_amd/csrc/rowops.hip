@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
                                                     int k, int stride, int rows) {
     constexpr int C = CPL * 64;
     const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;                                    // one grid row per utterance: no row -> utterance search
+    const int row_begin = foffs[b], row_end = foffs[b + 1];
     const int wglobal = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
     const int c0 = lane * CPL;
@@ -73,11 +75,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
         gr[i] = lg[c0 + i];
         be[i] = lb[c0 + i];
     }
-    for (int row = wglobal; row < rows; row += nwaves) {
-        int b = 0;
-        while (b + 1 < B && foffs[b + 1] <= row) ++b;            // B is small; wave-uniform scalar walk
-        const int t = row - foffs[b];
-        const float* xs = x + soffs[b] + (int64_t)t * stride;
+    const float* xb = x + soffs[b];
+    for (int row = row_begin + wglobal; row < row_end; row += nwaves) {
+        const int t = row - row_begin;
+        const float* xs = xb + (int64_t)t * stride;
         const float xv = lane < k ? xs[lane] : 0.f;
         float v[CPL];
 #pragma unroll
@@ -123,9 +124,11 @@ extern "C" int ser_conv0_ln_gelu(const float* wav_norm, const int64_t* sample_of
     if (!wav_norm || !sample_offs || !frame_offs || !w || !ln_g || !ln_b || !out) return ser_fail(-1, "ser_conv0: null pointer");
     if (k < 1 || k > 16 || stride < 1 || total_rows <= 0 || B <= 0) return ser_fail(-2, "ser_conv0: bad k/stride/rows");
     if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_conv0: bad mode");
-    int blocks = (total_rows + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    dim3 grid(blocks), block(256);
+    int blocks = ((total_rows + B - 1) / B + 3) / 4;          // average rows per utterance / 4 waves
+    const int cap = (256 * 16 + B - 1) / B;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    dim3 grid(blocks, B), block(256);
     hipStream_t s = (hipStream_t)stream;
     unsigned short* o = (unsigned short*)out;
 #define LAUNCH(CPL)                                                                                              \
@@ -246,6 +249,8 @@ extern "C" int ser_wavlm_bias_table(const float* rel_attn_embed, float* table, i
 
 // ------------------------------------------------------------------------------ K8b
 // gate[row,h] = a*(b*const_h - 1) + 2,  (a,b) = sigmoid(sum_{j<4} (w_j.x + b_j)), sigmoid(sum_{j>=4} ...)
+// Wave per row; a lane loads 16-byte chunks (8 channels of ONE head, dh % 8 == 0), so a head is a
+// group of dh/8 consecutive lanes and both dot products reduce with log2(dh/8) shuffles.
 template <int MODE>
 __global__ __launch_bounds__(256) void gate_kernel(const unsigned short* __restrict__ x, int64_t ldx, int64_t plane,
                                                    const float* __restrict__ w8, const float* __restrict__ b8,
@@ -254,35 +259,29 @@ __global__ __launch_bounds__(256) void gate_kernel(const unsigned short* __restr
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    // lane covers columns lane and lane+64 of a head (dh <= 128)
-    float wa0 = 0.f, wb0 = 0.f, wa1 = 0.f, wb1 = 0.f;
-    if (lane < dh) {
-        wa0 = (w8[0 * dh + lane] + w8[1 * dh + lane]) + (w8[2 * dh + lane] + w8[3 * dh + lane]);
-        wb0 = (w8[4 * dh + lane] + w8[5 * dh + lane]) + (w8[6 * dh + lane] + w8[7 * dh + lane]);
-    }
-    if (lane + 64 < dh) {
-        const int c = lane + 64;
-        wa1 = (w8[0 * dh + c] + w8[1 * dh + c]) + (w8[2 * dh + c] + w8[3 * dh + c]);
-        wb1 = (w8[4 * dh + c] + w8[5 * dh + c]) + (w8[6 * dh + c] + w8[7 * dh + c]);
+    const int lpg = dh >> 3;                                     // lanes per head (power of two)
+    const int d0 = (lane & (lpg - 1)) * 8;                       // this lane's offset inside its head
+    float wa[8], wb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wa[j] = (w8[0 * dh + d0 + j] + w8[1 * dh + d0 + j]) + (w8[2 * dh + d0 + j] + w8[3 * dh + d0 + j]);
+        wb[j] = (w8[4 * dh + d0 + j] + w8[5 * dh + d0 + j]) + (w8[6 * dh + d0 + j] + w8[7 * dh + d0 + j]);
     }
     const float ba = (b8[0] + b8[1]) + (b8[2] + b8[3]);
     const float bb = (b8[4] + b8[5]) + (b8[6] + b8[7]);
     const unsigned short* xr = x + (int64_t)row * ldx;
-    for (int h = 0; h < H; ++h) {
-        float x0 = 0.f, x1 = 0.f;
-        if (lane < dh) {
-            x0 = bf2f(xr[h * dh + lane]);
-            if (MODE == SER_MODE_FP32X) x0 += bf2f(xr[plane + h * dh + lane]);
-        }
-        if (lane + 64 < dh) {
-            x1 = bf2f(xr[h * dh + lane + 64]);
-            if (MODE == SER_MODE_FP32X) x1 += bf2f(xr[plane + h * dh + lane + 64]);
-        }
-        const float pa = wave_sum(x0 * wa0 + x1 * wa1) + ba;
-        const float pb = wave_sum(x0 * wb0 + x1 * wb1) + bb;
-        if (lane == 0) {
-            const float a = 1.f / (1.f + expf(-pa));
-            const float b = 1.f / (1.f + expf(-pb));
+    const int D = H * dh;
+    for (int c = lane * 8; c < D; c += 512) {
+        float v[8];
+        load_act8<MODE>(xr + c, plane, v);
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pa = fmaf(v[j], wa[j], pa); pb = fmaf(v[j], wb[j], pb); }
+        for (int o = lpg >> 1; o > 0; o >>= 1) { pa += __shfl_xor(pa, o, 64); pb += __shfl_xor(pb, o, 64); }
+        if ((lane & (lpg - 1)) == 0) {
+            const int h = c / dh;
+            const float a = 1.f / (1.f + expf(-(pa + ba)));
+            const float b = 1.f / (1.f + expf(-(pb + bb)));
             gate[(int64_t)row * H + h] = a * (b * gconst[h] - 1.f) + 2.f;
         }
     }
@@ -292,7 +291,8 @@ extern "C" int ser_wavlm_gate(const void* x_ln, int64_t ldx, int64_t plane_strid
                               const float* b8, const float* gru_const, float* gate, int rows, int H, int dh,
                               void* stream) {
     if (!x_ln || !w8 || !b8 || !gru_const || !gate) return ser_fail(-1, "ser_wavlm_gate: null pointer");
-    if (dh > 128 || dh <= 0 || rows <= 0) return ser_fail(-2, "ser_wavlm_gate: dh=%d unsupported", dh);
+    if ((dh != 8 && dh != 16 && dh != 32 && dh != 64 && dh != 128) || rows <= 0 || (ldx % 8))
+        return ser_fail(-2, "ser_wavlm_gate: dh=%d unsupported (8..128, power of two)", dh);
     dim3 grid((rows + 3) / 4), block(256);
     if (mode == SER_MODE_FP32X)
         hipLaunchKernelGGL(gate_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, (const unsigned short*)x_ln,

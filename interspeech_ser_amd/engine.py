@@ -101,6 +101,9 @@ class _EncoderBase:
         self.mode = MODES[mode]
         self.planes = 2 if mode == "fp32x" else 1
         self._cache: Dict = {}
+        # when a list, every ser_gemm launch appends (start_event, end_event, algorithmic_flops):
+        # bench.py uses it for the live roofline figure of the dominant kernel
+        self.gemm_trace: Optional[list] = None
 
     # ------------------------------------------------------------------ weights
     def _dev_f32(self, t: torch.Tensor) -> torch.Tensor:
@@ -123,7 +126,7 @@ class _EncoderBase:
     def _gemm(self, a: Act, lin: Linear, M: int, *, a_rowoff=None, lda=None, kc=0, ldj=0, groups=1,
               a_group_stride=0, w_group_stride=0, c_group_stride=0, N=None, K=None, act=_lib.ACT_NONE,
               residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
-              out_rowmap=None, a_ptr_offset=0):
+              out_rowmap=None, a_ptr_offset=0, k_algo=None):
         g = GemmArgs()
         g.A = a.ptr + a_ptr_offset
         g.a_plane_stride = a.plane_stride
@@ -147,7 +150,15 @@ class _EncoderBase:
         g.ldo_act = 0 if out_act is None else out_act.cols
         g.out_plane_stride = 0 if out_act is None else out_act.plane_stride
         g.out_rowmap = _ptr(out_rowmap)
+        if self.gemm_trace is None:
+            check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
+        e1.record()
+        # algorithmic FLOPs: 2*M*N*K over real (unpadded) channels, no tile-padding FLOPs
+        self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * (g.K if k_algo is None else k_algo)))
 
     def _layernorm(self, x: torch.Tensor, ldx: int, ln, rows: int, D: int, *, gelu=False, out_f32=None,
                    out_act: Optional[Act] = None, eps=None):
@@ -165,6 +176,23 @@ class _EncoderBase:
         check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
                                 max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
                                 H, dh, float(dh ** -0.5), self.mode, _stream()), "ser_attention")
+
+    def capture(self, packed_wave: torch.Tensor, lengths: Sequence[int]):
+        """Record one forward over a fixed batch shape into a hipGraph (via torch's CUDAGraph
+        plumbing).  A forward is ~230 short launches; replaying the graph removes the host-side
+        launch gaps that otherwise cost ~25 % of a step.  Returns (graph, hidden_states): the
+        states tensor is overwritten in place by every ``graph.replay()``."""
+        self._plan(lengths)                                  # buffers + offset tables allocated before capture
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.forward(packed_wave, lengths)               # warm-up on the side stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            hs = self.forward(packed_wave, lengths)
+        return graph, hs
 
     def _ln_pair(self, sd, prefix):
         return (self._dev_f32(sd[prefix + ".weight"]), self._dev_f32(sd[prefix + ".bias"]))
@@ -359,7 +387,7 @@ class SpeechEncoder(_EncoderBase):
         self._gemm(pl["halo_act"], self.pos, M, a_rowoff=pl["pos_rowoff"], kc=kc, ldj=D, groups=G,
                    a_group_stride=Cg, w_group_stride=Cg * geo.pos_conv_kernel * kc, c_group_stride=Cg,
                    N=Cg, K=geo.pos_conv_kernel * kc, act=_lib.ACT_GELU, residual=pl["proj_f32"], ldr=D,
-                   out_f32=states[0], ldo_f32=D)
+                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg)
         # a11/a12: stable-LayerNorm encoder layers
         L = geo.num_layers
         wavlm = geo.family == FAMILY_WAVLM
