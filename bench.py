@@ -49,28 +49,13 @@ def synth_batch(batch, num_samples, seed):
     return [(0.1 * torch.randn(num_samples, generator=g)).numpy() for _ in range(batch)]
 
 
-def broadcast_weights(geo, seed, rank, world, device):
+def broadcast_weights(geo, seed, rank):
     """C1: rank 0 owns the frozen weights; everyone else receives them over RCCL/xGMI in one
-    flat fp32 bucket.  With world == 1 this is just the synthetic init."""
+    flat fp32 bucket (interspeech_ser_amd/dist.py)."""
+    from interspeech_ser_amd import dist as D
     from interspeech_ser_amd.weights import synthetic_state_dict
-    import torch.distributed as dist
-    sd = synthetic_state_dict(geo, seed if rank == 0 else seed + 1 + rank)   # non-root values are overwritten
-    if world == 1:
-        return sd, 0.0
-    names = sorted(sd)
-    flat = torch.cat([sd[n].reshape(-1) for n in names]).to(device)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    dist.broadcast(flat, src=0)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    flat = flat.cpu()
-    o = 0
-    for n in names:
-        k = sd[n].numel()
-        sd[n] = flat[o:o + k].view_as(sd[n]).clone()
-        o += k
+    sd = synthetic_state_dict(geo, seed) if rank == 0 else None
+    sd, dt, _ = D.broadcast_state_dict(sd)
     return sd, dt
 
 
@@ -119,9 +104,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    from interspeech_ser_amd import dist as D
+    D.init("nccl" if world > 1 else None, device)
 
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import build_encoder
@@ -132,7 +116,7 @@ def main():
         raise SystemExit("bench.py measures the speech families; see DESIGN.md for the Whisper figures")
     num_samples = int(round(args.seconds * 16000))
 
-    sd, bcast_s = broadcast_weights(geo, 0, rank, world, device)
+    sd, bcast_s = broadcast_weights(geo, 0, rank)
     enc = build_encoder(geo, sd, device, args.mode)
     waves = synth_batch(args.batch, num_samples, 1234 + rank)
     lengths = [num_samples] * args.batch
@@ -168,10 +152,7 @@ def main():
         torch.cuda.synchronize()
         trace, enc.gemm_trace = enc.gemm_trace, None
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = D.max_over_ranks(elapsed)
 
     if rank == 0:
         total_utts = args.batch * args.steps * world
@@ -211,8 +192,7 @@ def main():
             from interspeech_ser_amd.weights import synthetic_state_dict
             out["cpu_baseline"] = cpu_baseline(geo, sd, num_samples)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,266 @@
+"""Extraction drivers: the counterparts of the reference's two scripts.
+
+``run_speech`` mirrors preprocessing/preprocess_speech.py and ``run_whisper``
+mirrors preprocessing/preprocess_whisper.py: same flags (:13-22 / :14-23), same
+stdout lines, same ``<save_path>/<basename>.pt`` files holding a bare [T, D]
+float32 CPU tensor, exit status 0 with per-file failures printed and skipped
+(:45-73).  What changes is underneath: files are length-bucketed into ragged
+batches, each batch is one packed forward on the GPU through libserhip, decode
+and ``torch.save`` run in ``--num_workers`` host threads around it, and with
+``torchrun`` the file list is sharded over ranks (one process per GPU).
+
+Deliberate, documented differences:
+* ``--n_layer`` is honoured by BOTH drivers (default -1 = last state).  The reference's
+  speech script parses it but then indexes ``hidden_states[N]`` with N = the number of
+  files already in ``--save_path`` at start-up (preprocess_speech.py:41,67), i.e. layer 0
+  on a fresh directory and a different layer on every re-run.  ``--compat_layer_quirk``
+  reproduces exactly that rule (N is taken once, on rank 0, before any rank writes).
+* additive flags: ``--batch_size``, ``--mode``, ``--checkpoint``, ``--synthetic_weights``,
+  ``--skip_existing``, ``--compat_layer_quirk``.  ``--seed`` (parsed and unused by the
+  reference) seeds the synthetic weights.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import config as C
+from .frontend import feature_path, load_wav_16k, save_feature, whisper_saved_rows
+
+
+# ------------------------------------------------------------------------------- CLI
+def build_parser(whisper: bool) -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    # the reference's flags, names and defaults unchanged (preprocess_speech.py:13-22)
+    p.add_argument("--seed", type=int, default=7)
+    p.add_argument("--ssl_type", type=str, default="wavlm-large")
+    p.add_argument("--save_path", type=str, default="./")
+    p.add_argument("--wav_dir", type=str, default="./")
+    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--n_layer", type=int, default=-1)
+    p.add_argument("--use_average", type=str, default="n")
+    # additive
+    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "bf16"],
+                   help="fp32x: fp32-grade results (1e-3 parity gate); bf16: fastest")
+    p.add_argument("--checkpoint", type=str, default="",
+                   help="local *.safetensors / pytorch_model.bin (or directory); default: HF cache lookup, "
+                        "else seeded synthetic weights")
+    p.add_argument("--skip_existing", action="store_true")
+    p.add_argument("--compat_layer_quirk", action="store_true",
+                   help="speech driver: index hidden_states with the number of files found in --save_path at "
+                        "start-up, like the reference does")
+    p.add_argument("--synthetic_weights", action="store_true",
+                   help="use seeded random weights of the right geometry (no network / benchmarking)")
+    return p
+
+
+from .dist import shard_files          # noqa: E402  (re-exported: the sharding rule lives in dist.py)
+
+
+def make_batches(files: Sequence[str], batch_size: int) -> List[List[str]]:
+    return [list(files[i:i + batch_size]) for i in range(0, len(files), batch_size)]
+
+
+def resolve_layer_index(n_layer: int, num_states: int) -> int:
+    idx = n_layer if n_layer >= 0 else num_states + n_layer
+    if not 0 <= idx < num_states:
+        raise IndexError("tuple index out of range")     # what hidden_states[N] raises in the reference
+    return idx
+
+
+# ------------------------------------------------------------------------ weights
+def find_weights(ssl_type: str, checkpoint: str, synthetic: bool, seed: int, geo):
+    """Rank 0 only: the other ranks receive the tensors by broadcast (dist.broadcast_state_dict)."""
+    from .weights import load_checkpoint, synthetic_state_dict
+    if checkpoint:
+        return load_checkpoint(checkpoint), f"checkpoint {checkpoint}"
+    if not synthetic:
+        # offline HF cache layout: $HF_HOME/hub/models--org--name/snapshots/<rev>/
+        home = os.environ.get("HF_HOME", os.path.join(os.path.expanduser("~"), ".cache", "huggingface"))
+        snap = os.path.join(home, "hub", "models--" + ssl_type.replace("/", "--"), "snapshots")
+        if os.path.isdir(snap):
+            for rev in sorted(os.listdir(snap)):
+                try:
+                    return load_checkpoint(os.path.join(snap, rev)), f"HF cache {rev}"
+                except OSError:
+                    continue
+        raise OSError(f"no local checkpoint for {ssl_type} (pass --checkpoint or --synthetic_weights)")
+    return synthetic_state_dict(geo, seed), f"synthetic weights (seed {seed})"
+
+
+# ------------------------------------------------------------------------ the loop
+class _Extractor:
+    def __init__(self, args, whisper: bool, device: str):
+        from .engine import build_encoder
+        self.args, self.whisper = args, whisper
+        self.geo = C.geometry_for(args.ssl_type)
+        if whisper != (self.geo.family == C.FAMILY_WHISPER):
+            raise OSError(f"{args.ssl_type} is not a {'whisper' if whisper else 'wav2vec2-style'} encoder")
+        from . import dist as D
+        rank = D.env()[0]
+        sd, err = None, ""
+        self.weight_source = "broadcast from rank 0"
+        if rank == 0:
+            try:
+                sd, self.weight_source = find_weights(args.ssl_type, args.checkpoint, args.synthetic_weights,
+                                                      args.seed, self.geo)
+            except OSError as e:
+                err = str(e)
+        if D.broadcast_int(1 if (rank == 0 and sd is None) else 0) == 1:
+            raise OSError(err or "rank 0 found no checkpoint")
+        sd, self.bcast_s, self.bcast_bytes = D.broadcast_state_dict(sd)
+        self.enc = build_encoder(self.geo, sd, device, args.mode)
+        self.average = args.use_average == "y"
+
+    def extract(self, waves: List[np.ndarray], layer_index: int) -> List[torch.Tensor]:
+        """One ragged batch -> one CPU [T, D] tensor per utterance (rows a19/a20)."""
+        from .engine import mean_last4
+        lengths = [len(w) for w in waves]
+        hs = self.enc.forward(self.enc.upload(waves), lengths)
+        sel = mean_last4(hs) if self.average else hs.states[layer_index]
+        out = []
+        host = sel.to("cpu", non_blocking=False)
+        for b, n in enumerate(lengths):
+            rows = host[hs.frame_offs[b]: hs.frame_offs[b + 1]]
+            if self.whisper:
+                rows = rows[: whisper_saved_rows(n, rows.shape[1])]
+            out.append(rows)
+        return out
+
+
+def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
+    from . import dist as D
+    args = build_parser(whisper).parse_args(argv)
+    rank, world, local_rank = D.env()
+    average = args.use_average == "y"
+    log = print if rank == 0 else (lambda *a, **k: None)
+    log(f"Using average = {average}")
+    device = f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"
+    log(f"Using device = {'cuda' if torch.cuda.is_available() else 'cpu'}")
+    os.makedirs(args.save_path, exist_ok=True)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    D.init(device=torch.device("cuda", local_rank) if torch.cuda.is_available() else None)
+    # taken once on rank 0 before anybody writes: ranks must not race on len(listdir)
+    n_existing = D.broadcast_int(len(os.listdir(args.save_path)) if rank == 0 else 0)
+    log(f"Save path = {args.save_path} created. It has {n_existing} files in it.")
+
+    wav_names = os.listdir(args.wav_dir)
+    log(f"{len(wav_names)} file are going to be processed...")
+    log(f"Checking files in {args.wav_dir}")
+    missing = [os.path.join(args.wav_dir, w) for w in wav_names if not os.path.isfile(os.path.join(args.wav_dir, w))]
+    if missing:
+        log("Missing files:")
+        for m in missing:
+            log(f" - {m}")
+        log("Something went wrong, make sure everything is correct before running again!")
+        return 0
+
+    log(f"Extracting features using {args.ssl_type}")
+    if device == "cpu":
+        # the product has exactly one backend; say so instead of silently computing elsewhere
+        print("Error: no MI355X visible -- this build has no CPU path (the CPU oracle under oracle/ is test-only)")
+        print("Something went wrong, make sure everything is correct before running again!")
+        D.shutdown()
+        return 0
+    try:
+        ex = _Extractor(args, whisper, device)
+    except OSError as e:
+        log(f"Error: No pretrained model found with the name {args.ssl_type}")
+        log(f"  ({e})")
+        log("Something went wrong, make sure everything is correct before running again!")
+        D.shutdown()
+        return 0
+    log(f"Weights: {ex.weight_source}; numerics mode {args.mode}")
+
+    num_states = ex.geo.num_layers + 1
+    if whisper:
+        layer_index = None if average else resolve_layer_index(args.n_layer, num_states)
+    elif args.compat_layer_quirk:
+        layer_index = n_existing                         # preprocess_speech.py:41,67 (may be out of range -> per-file failure)
+    else:
+        layer_index = None if average else resolve_layer_index(args.n_layer, num_states)
+
+    paths = [os.path.join(args.wav_dir, w) for w in sorted(wav_names)]
+    if args.skip_existing:
+        paths = [p for p in paths if not os.path.isfile(feature_path(args.save_path, p))]
+    sizes = [os.path.getsize(p) for p in paths]
+    mine = shard_files(paths, sizes, rank, world)
+    batches = make_batches(mine, max(1, args.batch_size))
+
+    def decode(path):
+        try:
+            return path, load_wav_16k(path), None
+        except Exception as e:                            # noqa: BLE001  (reference: except Exception -> print)
+            return path, None, e
+
+    def write(item):
+        path, feats = item
+        try:
+            save_feature(feats, feature_path(args.save_path, path))
+        except Exception as e:                            # noqa: BLE001
+            print(f"Failed to process {path}: {e}")
+
+    from tqdm import tqdm
+    t0 = time.perf_counter()
+    done = 0
+    audio_s = 0.0
+    bar = tqdm(total=len(mine), desc="Extracting features", disable=(rank != 0))
+    with ThreadPoolExecutor(max_workers=max(1, args.num_workers)) as pool:
+        pending = pool.map(decode, batches[0]) if batches else []
+        writes = []
+        for bi, batch in enumerate(batches):
+            decoded = list(pending)
+            if bi + 1 < len(batches):
+                pending = pool.map(decode, batches[bi + 1])          # decode the next batch while the GPU works
+            good = []
+            for path, wave, err in decoded:
+                if err is not None:
+                    print(f"Failed to process {path}: {err}")
+                else:
+                    good.append((path, wave))
+            if good:
+                try:
+                    if layer_index is not None and not 0 <= layer_index < num_states:
+                        raise IndexError("tuple index out of range")
+                    feats = ex.extract([w for _, w in good], layer_index)
+                    for (path, wave), f in zip(good, feats):
+                        writes.append(pool.submit(write, (path, f)))
+                        audio_s += len(wave) / 16000.0
+                    done += len(good)
+                except Exception as e:                    # noqa: BLE001
+                    # a failed batch is retried per utterance so one bad file cannot drop its neighbours
+                    for path, wave in good:
+                        try:
+                            f = ex.extract([wave], layer_index)[0]
+                            writes.append(pool.submit(write, (path, f)))
+                            done += 1
+                            audio_s += len(wave) / 16000.0
+                        except Exception as e1:           # noqa: BLE001
+                            print(f"Failed to process {path}: {e1}")
+            bar.update(len(batch))
+        for w in writes:
+            w.result()
+    bar.close()
+    dt = time.perf_counter() - t0
+    total_done, wall = D.sum_over_ranks(done), D.max_over_ranks(dt)
+    log(f"{int(total_done)} utterances on {world} GPU(s) in {wall:.2f} s ({total_done / max(wall, 1e-9):.1f} utt/s)")
+    D.shutdown()
+    return 0
+
+
+def run_speech(argv: Optional[Sequence[str]] = None) -> int:
+    return _run(argv, whisper=False)
+
+
+def run_whisper(argv: Optional[Sequence[str]] = None) -> int:
+    return _run(argv, whisper=True)

@@ -1,0 +1,68 @@
+"""CPU: libserhip.so builds for gfx950, loads, and exports exactly the C ABI of include/ser_hip.h."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ser_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ser_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    lib = ctypes.CDLL(built_library)
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in ser_hip.h but not exported"
+
+
+def test_binding_covers_header(built_library):
+    from interspeech_ser_amd import _lib
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
+    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 1
+
+
+def test_gemm_args_layout_matches_c(built_library, tmp_path):
+    """The ctypes mirror of ser_gemm_args must have the C compiler's size and offsets."""
+    from interspeech_ser_amd._lib import GemmArgs
+    fields = [f[0] for f in GemmArgs._fields_]
+    src = tmp_path / "layout.c"
+    body = "\n".join(f'printf("{f} %zu\\n", offsetof(ser_gemm_args, {f}));' for f in fields)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\n'
+                   f'int main(void){{printf("sizeof %zu\\n", sizeof(ser_gemm_args));{body}return 0;}}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(out["sizeof"]) == ctypes.sizeof(GemmArgs)
+    for f in fields:
+        assert int(out[f]) == getattr(GemmArgs, f).offset, f
+
+
+def test_argument_errors_are_reported_not_raised(built_library):
+    """Launchers return <0 and set ser_last_error() on bad arguments (no GPU needed: validation
+    happens before any launch)."""
+    from interspeech_ser_amd import _lib
+    g = _lib.GemmArgs()
+    assert _lib.lib.ser_gemm(ctypes.byref(g), None) < 0
+    assert b"ser_gemm" in _lib.lib.ser_last_error()
+    assert _lib.lib.ser_layernorm(None, 0, None, None, 1e-5, 0, None, 0, None, 0, 0, 1, 1, 8, None) < 0
+    assert _lib.lib.ser_attention(None, 0, 0, 0, 0, 0, None, 1, 1, None, 0, None, None, 0, 0, 1, 64, 0.125, 1, None) < 0
+    assert _lib.lib.ser_workspace_bytes(_lib.WS_LOGMEL, 4, 0, 0, 0, 1) == 4 * 256 + 400 * 201 * 16
+
+
+def test_engine_refuses_to_run_without_a_gpu(built_library):
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd._lib import SerHipError
+    from interspeech_ser_amd.engine import SpeechEncoder
+    with pytest.raises(SerHipError):
+        SpeechEncoder(C.TINY_WAVLM, {}, "cuda:0")

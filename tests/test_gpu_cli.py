@@ -1,0 +1,83 @@
+"""-m gpu: the drivers end to end (BASELINE.json configs[0]: 8 synthetic 3 s wavs -> 8 .pt of
+shape [149, 1024]) and the Whisper driver's crop rule, through files on disk."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def write_wav(path, x):
+    pcm = (np.clip(x, -1, 1) * 32767).astype("<i2")
+    with wave.open(str(path), "wb") as wf:
+        wf.setnchannels(1)
+        wf.setsampwidth(2)
+        wf.setframerate(16000)
+        wf.writeframes(pcm.tobytes())
+    return pcm.astype(np.float32) / 32768.0
+
+
+def synth(seed, n):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    return 0.1 * rng.standard_normal(n) + 0.2 * np.sin(2 * np.pi * 220 * t)
+
+
+def test_speech_driver_config0(tmp_path, capsys):
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    wav_dir, out = tmp_path / "wavs", tmp_path / "feats"
+    wav_dir.mkdir()
+    waves = {}
+    for i in range(8):
+        n = 48000 if i < 6 else 48000 - 777 * i            # two ragged ones
+        waves[f"syn_{i:04d}"] = write_wav(wav_dir / f"syn_{i:04d}.wav", synth(7 + i, n))
+    (wav_dir / "broken.wav").write_bytes(b"not a wav file")
+    rc = driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", str(wav_dir), "--save_path", str(out),
+                            "--synthetic_weights", "--n_layer", "0", "--batch_size", "5"])
+    text = capsys.readouterr().out
+    assert rc == 0
+    assert "Using device = cuda" in text and "9 file are going to be processed..." in text
+    assert "Failed to process" in text and "broken.wav" in text      # logged and skipped, like the reference
+    files = sorted(os.listdir(out))
+    assert files == [f"syn_{i:04d}.pt" for i in range(8)]
+    geo = C.WAVLM_LARGE
+    sd = synthetic_state_dict(geo, 7)                                  # --seed default
+    for name in ("syn_0000", "syn_0007"):
+        got = torch.load(out / f"{name}.pt")
+        w = waves[name]
+        assert got.dtype == torch.float32 and got.device.type == "cpu"
+        assert tuple(got.shape) == (geo.frames_for(len(w)), 1024)
+        ref = O.extract_speech(geo, sd, w, layer_index=0)
+        assert float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
+    assert tuple(torch.load(out / "syn_0000.pt").shape) == (149, 1024)
+
+    # compat quirk: 8 files now in save_path -> hidden_states[8]; and --use_average
+    rc = driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", str(wav_dir), "--save_path", str(out),
+                            "--synthetic_weights", "--compat_layer_quirk", "--batch_size", "8"])
+    assert rc == 0
+    got = torch.load(out / "syn_0001.pt")
+    with torch.no_grad():
+        ref = O.extract_speech(geo, sd, waves["syn_0001"], layer_index=8)
+    assert float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
+
+
+def test_whisper_driver_crop(tmp_path, capsys):
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    wav_dir, out = tmp_path / "wavs", tmp_path / "feats"
+    wav_dir.mkdir()
+    write_wav(wav_dir / "short.wav", synth(1, 16000))
+    write_wav(wav_dir / "long.wav", synth(2, 16000 * 29))
+    rc = driver.run_whisper(["--ssl_type", "openai/whisper-large-v3", "--wav_dir", str(wav_dir), "--save_path", str(out),
+                             "--synthetic_weights", "--mode", "bf16"])
+    assert rc == 0, capsys.readouterr().out
+    a, b = torch.load(out / "short.pt"), torch.load(out / "long.pt")
+    assert tuple(a.shape) == (50, 1280)                                # ceil(16000/320)
+    assert tuple(b.shape) == (1280, 1280)                              # capped by the hidden size (reference quirk)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()

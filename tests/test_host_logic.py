@@ -1,0 +1,128 @@
+"""CPU: host-side logic of the drivers (rows a1-a5, a8, a19-a21 of SURVEY 8a)."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from interspeech_ser_amd import config as C
+from interspeech_ser_amd import driver, frontend
+from interspeech_ser_amd.dist import shard_files
+
+
+def write_wav(path, x, sr=16000, ch=1):
+    pcm = (np.clip(x, -1, 1) * 32767).astype("<i2")
+    with wave.open(str(path), "wb") as wf:
+        wf.setnchannels(ch)
+        wf.setsampwidth(2)
+        wf.setframerate(sr)
+        wf.writeframes(pcm.tobytes())
+    return pcm
+
+
+def test_cli_surface_matches_reference():
+    """Flag names and defaults of preprocess_speech.py:13-22 / preprocess_whisper.py:14-23."""
+    for whisper in (False, True):
+        a = driver.build_parser(whisper).parse_args([])
+        assert (a.seed, a.ssl_type, a.save_path, a.wav_dir, a.num_workers, a.n_layer, a.use_average) == \
+               (7, "wavlm-large", "./", "./", 4, -1, "n")
+
+
+def test_geometry_registry():
+    assert C.geometry_for("microsoft/wavlm-large").hidden == 1024
+    assert C.geometry_for("wavlm-large") is C.WAVLM_LARGE
+    assert C.geometry_for("facebook/wav2vec2-xls-r-2b").head_dim == 120
+    assert C.geometry_for("facebook/hubert-xlarge-ls960-ft").head_dim == 80
+    assert C.geometry_for("openai/whisper-large-v3").num_hidden_states == 33
+    with pytest.raises(OSError):
+        C.geometry_for("no/such-model")
+
+
+def test_frame_arithmetic():
+    g = C.WAVLM_LARGE
+    assert g.frame_chain(160000) == [31999, 15999, 7999, 3999, 1999, 999, 499]
+    assert g.frames_for(48000) == 149 and g.frames_for(400) == 1 and g.frames_for(399) == 0
+
+
+def test_wav_decode_matches_soundfile_convention(tmp_path):
+    rng = np.random.default_rng(0)
+    x = 0.3 * rng.standard_normal(4000)
+    pcm = write_wav(tmp_path / "a.wav", x)
+    y = frontend.load_wav_16k(str(tmp_path / "a.wav"))
+    assert y.dtype == np.float32 and np.array_equal(y, pcm.astype(np.float32) / 32768.0)
+    st = np.stack([x, -0.5 * x], axis=1).reshape(-1)
+    write_wav(tmp_path / "s.wav", st, ch=2)
+    ys = frontend.load_wav_16k(str(tmp_path / "s.wav"))
+    assert ys.shape == (4000,)
+    write_wav(tmp_path / "r.wav", x, sr=8000)
+    with pytest.raises(frontend.UnsupportedAudio):
+        frontend.load_wav_16k(str(tmp_path / "r.wav"))
+
+
+def test_feature_file_contract(tmp_path):
+    """<save_path>/<basename>.pt, bare 2-D float32 CPU tensor loadable with torch.load
+    (bin/train_cat_bimodal_lazy_1head.py:220-228 in the reference)."""
+    p = frontend.feature_path(str(tmp_path), "/data/wavs/MSP-PODCAST_0001_0008.wav")
+    assert p == os.path.join(str(tmp_path), "MSP-PODCAST_0001_0008.pt")
+    feats = torch.arange(12, dtype=torch.float32).view(4, 3)
+    frontend.save_feature(feats[:3], p)
+    back = torch.load(p)
+    assert back.dtype == torch.float32 and back.ndim == 2 and back.device.type == "cpu"
+    assert torch.equal(back, feats[:3]) and back.untyped_storage().nbytes() == 3 * 3 * 4
+
+
+def test_whisper_crop_and_mel(golden_dir):
+    g = np.load(os.path.join(golden_dir, "integer_tables.npz"))
+    for n, r in zip(g["whisper_len"], g["whisper_rows"]):
+        assert frontend.whisper_saved_rows(int(n), 1280) == int(r)
+    assert frontend.whisper_saved_rows(480000, 1280) == 1280            # the reference's cap is the hidden size
+    assert np.abs(frontend.whisper_mel_filters(128) - g["mel_filters"]).max() < 1e-7
+
+
+def test_layer_index_rules():
+    assert driver.resolve_layer_index(-1, 25) == 24
+    assert driver.resolve_layer_index(0, 25) == 0
+    with pytest.raises(IndexError):
+        driver.resolve_layer_index(25, 25)
+
+
+def test_sharding_is_a_balanced_partition():
+    files = [f"u{i:03d}.wav" for i in range(37)]
+    sizes = [1000 + (i * 7919) % 5000 for i in range(37)]
+    shards = [shard_files(files, sizes, r, 4) for r in range(4)]
+    assert sorted(sum(shards, [])) == sorted(files)
+    tot = [sum(sizes[files.index(f)] for f in s) for s in shards]
+    assert max(tot) - min(tot) <= max(sizes)
+    for s in shards:
+        sz = [sizes[files.index(f)] for f in s]
+        assert sz == sorted(sz, reverse=True)
+    assert driver.make_batches(shards[0], 4)[0] == shards[0][:4]
+
+
+def test_driver_without_gpu_logs_and_exits_zero(tmp_path, capsys):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    wav_dir, out = tmp_path / "w", tmp_path / "o"
+    wav_dir.mkdir()
+    write_wav(wav_dir / "a.wav", np.zeros(1600))
+    rc = driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", str(wav_dir), "--save_path", str(out)])
+    text = capsys.readouterr().out
+    assert rc == 0
+    assert "Using average = False" in text and "1 file are going to be processed..." in text
+    assert f"Save path = {out} created. It has 0 files in it." in text
+    assert "no CPU path" in text and not list(out.iterdir())
+
+
+def test_synthetic_weights_have_hf_names_and_shapes():
+    from interspeech_ser_amd.weights import normalize_names, synthetic_state_dict
+    sd = synthetic_state_dict(C.TINY_WAVLM, 1)
+    assert sd["encoder.layers.0.attention.rel_attn_embed.weight"].shape == (320, 2)
+    assert "encoder.layers.1.attention.rel_attn_embed.weight" not in sd
+    assert sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"].shape == (128, 64, 128)
+    assert "feature_extractor.conv_layers.0.conv.bias" not in sd
+    sd2 = synthetic_state_dict(C.TINY_HUBERT, 1)
+    assert "feature_extractor.conv_layers.0.conv.bias" in sd2
+    wrapped = {"wav2vec2." + k: v for k, v in sd2.items()}
+    wrapped["lm_head.weight"] = torch.zeros(2, 2)
+    assert sorted(normalize_names(wrapped)) == sorted(sd2)
