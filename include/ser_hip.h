@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 1
+#define SER_ABI_VERSION 2
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -68,6 +68,7 @@ int ser_conv0_ln_gelu(const float* wav_norm, const int64_t* sample_offs, const i
  * nn.Linear (:133-136, :288-294) are the same kernel.  Epilogue order:
  *   v = acc + bias[n];  v = act(v);  v += residual[(m % res_row_mod or m)*ldr + n];
  *   out_f32[m*ldo_f32 + n] = v;   out_act[out_row(m)*ldo_act + n] = split(v)
+ * With ln_gamma != NULL the epilogue is  v = act(LayerNorm_row(acc + bias)) instead.
  * Requirements: K % 64 == 0, kc % 64 == 0, N % 8 == 0, all row starts 16-byte aligned. */
 typedef struct ser_gemm_args {
     const void*    A;              /* act (bf16 planes) */
@@ -95,6 +96,13 @@ typedef struct ser_gemm_args {
     int64_t        ldo_act;
     int64_t        out_plane_stride;
     const int32_t* out_rowmap;     /* [M] row index in out_act, or NULL (identity) */
+    /* optional fused LayerNorm over the full output row (conv stack: Conv1d -> LayerNorm(C) -> GELU,
+     * HF modeling_wavlm.py:712-719): v = LN(acc + bias) * gamma + beta, then act.  Needs N <= 512,
+     * groups == 1, no residual. */
+    const float*   ln_gamma;       /* [N] or NULL */
+    const float*   ln_beta;        /* [N] */
+    float          ln_eps;
+    int32_t        tile_cfg;       /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile */
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
 

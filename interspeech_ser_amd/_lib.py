@@ -17,7 +17,7 @@ MODE_FP32X = 2
 ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("out_f32", c_void_p), ("ldo_f32", c_i64),
         ("out_act", c_void_p), ("ldo_act", c_i64), ("out_plane_stride", c_i64),
         ("out_rowmap", c_void_p),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("tile_cfg", C.c_int32),
     ]
 
 

@@ -10,16 +10,25 @@
 //   * O^T = V^T P^T reuses the S^T accumulator as the MFMA B operand with no data
 //     movement (registers 8s..8s+7 -> k-step s); V^T is the A operand and is produced
 //     from the row-major V tile by ds_read_b64_tr_b16 (hardware transpose read).
-//     O^T has the query on the lane as well, so the rescale by exp(m_old-m_new) is lane-local.
-//   * WavLM's gated relative bias needs only the 2T-1 distinct distances: the head's
-//     table row is staged once in LDS and indexed by (key - query).
+//     O^T has the query on the lane as well, so the rescale by 2^(m_old-m_new) is lane-local
+//     and is skipped (wave-uniform branch) when no row maximum moved.
+//   * K/V tiles are double-buffered in LDS with an issue-early / write-late register stage:
+//     the global loads of tile t+1 are issued before the MFMAs of tile t and written to the
+//     other LDS buffer after them -> one barrier per tile, HBM/L2 latency under compute.
+//   * softmax in the exp2 domain: score*log2(e) folded into the one FMA that applies scale and
+//     bias, v_exp_f32 directly; the key-padding select only exists in the last (ragged) tile.
+//   * WavLM's gated relative bias needs only the 2T-1 distinct distances: the head's table row is
+//     staged once in LDS as 4 copies shifted by 0..3 elements, so the 4 consecutive keys a
+//     register quad holds are ONE aligned ds_read_b128 whatever (key - query) mod 4 is.
 //   * LDS images: K rows XOR-swizzled for conflict-free ds_read_b128 row reads, V 64-byte
 //     units XOR-swizzled so the 4 keys of a transposed read hit 4 different bank quarters.
 //   * FP32X mode: every product is the 3-term bf16 split (hi*hi + lo*hi + hi*lo).
 #include "ser_common.h"
+#include <type_traits>
 
 #define ABQ 128      // query rows per block
 #define ABKV 64      // keys per tile
+#define LOG2E 1.4426950408889634f
 
 struct AttnParams {
     const unsigned short* qkv;
@@ -32,6 +41,7 @@ struct AttnParams {
     unsigned short* out;
     int64_t ldo, out_plane;
     int H, dh;
+    int bias_stride;      // floats per shifted bias copy in LDS
     float scale;
 };
 
@@ -45,17 +55,19 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 }
 
 template <int DHP, int MODE>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2) void attention_kernel(const AttnParams p) {
     constexpr int NP = (MODE == SER_MODE_FP32X) ? 2 : 1;
     constexpr int RS = DHP * 2;                 // LDS row bytes
     constexpr int KS = DHP / 16;                // QK^T k-steps
     constexpr int DSUB = DHP / 32;              // 32-wide output column blocks
     constexpr int CPR = DHP / 8;                // 16-byte chunks per row
     constexpr int TILE = ABKV * RS;             // bytes of one K or V plane tile
+    constexpr int NCH = ABKV * CPR / 256;       // staged 16-B chunks per thread per plane per operand
+    constexpr bool DB = (NCH * 2 * NP) <= 8;    // double-buffer when the register stage is <= 32 VGPRs
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int BUF = 2 * NP * TILE;          // one K+V buffer
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsK = smem;                          // [NP][64][RS]
-    char* ldsV = smem + NP * TILE;              // [NP][64][RS]
-    float* ldsB = (float*)(smem + 2 * NP * TILE);
+    float* ldsB = (float*)(smem + NBUF * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,11 +78,71 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     if (q0 >= T) return;
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
+    const int nkt = (T + ABKV - 1) / ABKV;
 
-    // ---- stage this head's bias row: ldsB[i] = table[h][(table_T-1) - (T-1) + i], i < 2T-1
+    // ---- staging helpers: thread owns chunks c = tid + i*256 of the [64 keys][CPR] tile --------
+    u32x4 stg[NP][2][NCH];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * 256;
+            const int key = c / CPR, ch = c - key * CPR;
+            const int kg = kt * ABKV + key;
+            // branch-free: always load from a valid address, zero by select (keys >= T, pad columns >= dh)
+            const bool ok = (kg < T) && (ch * 8 < dh);
+            const unsigned short* src = p.qkv + (int64_t)(row0 + (kg < T ? kg : T - 1)) * p.ld + h * dh
+                                      + (ch * 8 < dh ? ch * 8 : 0);
+            const unsigned int keep = ok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                u32x4 kv = *(const u32x4*)(src + p.k_col + pl * p.plane);
+                u32x4 vv = *(const u32x4*)(src + p.v_col + pl * p.plane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { kv[e] &= keep; vv[e] &= keep; }
+                stg[pl][0][i] = kv;
+                stg[pl][1][i] = vv;
+            }
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * 256;
+            const int key = c / CPR, ch = c - key * CPR;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                *(u32x4*)(base + pl * TILE + key * RS + (k_swz<DHP>(key, ch) << 4)) = stg[pl][0][i];
+                *(u32x4*)(base + NP * TILE + pl * TILE + key * RS + (v_unit_swz<DHP>(key, ch >> 2) << 6) + ((ch & 3) << 4)) = stg[pl][1][i];
+            }
+        }
+    };
+
+    stage_load(0);
+
+    // ---- this head's bias row, 4 shifted copies: copy c [j] = table[h][(table_T-T) + j + c] -------
     if (p.table) {
+        // each table element is read ONCE (5 independent loads in flight per thread and pass) and
+        // scattered into the 4 shifted copies; indices past 2T-1 are written as zeros (tail padding)
         const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T);
-        for (int i = tid; i < 2 * T - 1; i += 256) ldsB[i] = trow[i];
+        const int n = 2 * T - 1, span = p.bias_stride + 3;
+        for (int base = 0; base < span; base += 5 * 256) {
+            float v[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int idx = base + u * 256 + tid;
+                v[u] = idx < n ? trow[idx] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int idx = base + u * 256 + tid;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = idx - c;
+                    if (j >= 0 && j < p.bias_stride) ldsB[c * p.bias_stride + j] = v[u];
+                }
+            }
+        }
     }
 
     // ---- Q fragments: lane holds Q[q][16*ks + 8*hh + j]
@@ -89,7 +161,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                 qf[pl][ks] = __builtin_bit_cast(bf16x8, v);
             }
     }
-    const float gq = p.gate ? p.gate[(int64_t)(row0 + qc) * p.H + h] : 0.f;
+    const float c1 = p.scale * LOG2E;
+    const float gq2 = p.gate ? p.gate[(int64_t)(row0 + qc) * p.H + h] * LOG2E : 0.f;
+    // aligned bias window: index of key kb (multiple of 4) is kb - qc + T-1 = a + sh with a % 4 == 0
+    const int bsh = (T - 1 - qc) & 3;
+    const float* bcopy = ldsB + bsh * p.bias_stride + ((T - 1 - qc) - bsh);
 
     f32x16 ot[DSUB];
 #pragma unroll
@@ -98,28 +174,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    const int nkt = (T + ABKV - 1) / ABKV;
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();                                            // previous tile fully consumed
-        // ---- stage K and V tiles (zero-filled beyond T and beyond dh)
-        for (int c = tid; c < ABKV * CPR; c += 256) {
-            const int key = c / CPR, ch = c - key * CPR;
-            const int kg = kt * ABKV + key;
-            const bool ok = (kg < T) && (ch * 8 < dh);
-            const unsigned short* src = p.qkv + (int64_t)(row0 + (kg < T ? kg : T - 1)) * p.ld + h * dh + ch * 8;
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-                if (ok) {
-                    kv = *(const u32x4*)(src + p.k_col + pl * p.plane);
-                    vv = *(const u32x4*)(src + p.v_col + pl * p.plane);
-                }
-                *(u32x4*)(ldsK + pl * TILE + key * RS + (k_swz<DHP>(key, ch) << 4)) = kv;
-                const int unit = ch >> 2;
-                *(u32x4*)(ldsV + pl * TILE + key * RS + (v_unit_swz<DHP>(key, unit) << 6) + ((ch & 3) << 4)) = vv;
-            }
-        }
-        __syncthreads();
+    stage_write(0);
+    __syncthreads();
+
+    auto tile = [&](int kt, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        const int cur = DB ? (kt & 1) : 0;
+        const char* ldsK = smem + cur * BUF;
+        const char* ldsV = ldsK + NP * TILE;
+        if (DB && kt + 1 < nkt) stage_load(kt + 1);                 // issue early: lands under the MFMAs below
 
         // ---- S^T = K Q^T  (rows = keys in registers, col = query on the lane)
         f32x16 st[2];
@@ -141,38 +204,44 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             }
         }
 
-        // ---- scores, online softmax (lane-local rows)
+        // ---- scores (log2 domain) and running max
         float mloc = -1e30f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * ABKV + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = st[sub][r] * p.scale;
-                if (p.table) v += gq * ldsB[key < T ? key - qc + (T - 1) : 0];
-                v = key < T ? v : -INFINITY;
-                st[sub][r] = v;
-                mloc = fmaxf(mloc, v);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.table) bv = *(const f32x4*)(bcopy + kb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(st[sub][4 * g4 + r], c1, gq2 * bv[r]);
+                    if (RAGGED) v = (kb + r < T) ? v : -INFINITY;
+                    st[sub][4 * g4 + r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(st[sub][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(st[sub][r] - m_new);
                 st[sub][r] = e;
                 lsum += e;
             }
         lsum += __shfl_xor(lsum, 32, 64);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                                 // wave-uniform: most tiles after the first few skip it
 #pragma unroll
-        for (int i = 0; i < DSUB; ++i)
+            for (int i = 0; i < DSUB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T : accumulator registers 8s..8s+7 are the B fragment of k-step s
 #pragma unroll
@@ -211,7 +280,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                     }
                 }
             }
-    }
+
+        // ---- publish the next tile
+        if (kt + 1 < nkt) {
+            if (DB) {
+                stage_write(cur ^ 1);                                // write late: other buffer, nobody reads it now
+                __syncthreads();
+            } else {
+                __syncthreads();                                     // everyone done with the single buffer
+                stage_load(kt + 1);
+                stage_write(0);
+                __syncthreads();
+            }
+        }
+    };
+    // the key-padding select exists only in the last tile of a ragged utterance
+    const int nfull = (T & (ABKV - 1)) ? nkt - 1 : nkt;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nkt - 1, std::true_type{});
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane owns query q, 4 consecutive d per register quad
     if (q < T) {
@@ -229,6 +315,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
 }
 
+template <int DHP, int MODE>
+static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
+    auto k = attention_kernel<DHP, MODE>;
+    static bool ready = false;
+    if (lds > 65536 && !ready) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return ser_fail((int)e, "ser_attention: cannot raise dynamic LDS");
+        ready = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+    return ser_check_launch("ser_attention");
+}
+
 extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
                              const int32_t* frame_offs, int B, int max_frames, const float* table, int table_T,
                              const float* gate, void* out, int64_t ldo, int64_t out_plane_stride, int H, int dh,
@@ -242,19 +341,21 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     if (table && table_T < max_frames) return ser_fail(-7, "ser_attention: bias table built for T=%d < max_frames=%d", table_T, max_frames);
     const int dhp = dh <= 64 ? 64 : 128;
     const int np = mode == SER_MODE_FP32X ? 2 : 1;
-    const size_t lds = (size_t)2 * np * ABKV * dhp * 2 + (table ? (size_t)(2 * max_frames) * 4 : 0);
-    if (lds > 65536) return ser_fail(-8, "ser_attention: LDS need %zu > 64 KiB (max_frames=%d)", lds, max_frames);
+    const int nch = ABKV * (dhp / 8) / 256;
+    const int nbuf = (nch * 2 * np <= 8) ? 2 : 1;
+    const int bias_stride = table ? ((2 * max_frames + ABKV + 3) / 4) * 4 : 0;
+    const size_t lds = (size_t)nbuf * 2 * np * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
+    if (lds > 160 * 1024) return ser_fail(-8, "ser_attention: LDS need %zu > 160 KiB (max_frames=%d)", lds, max_frames);
     AttnParams p;
     p.qkv = (const unsigned short*)qkv; p.ld = ld; p.plane = plane_stride;
     p.q_col = q_col; p.k_col = k_col; p.v_col = v_col;
     p.frame_offs = frame_offs; p.table = table; p.table_T = table_T; p.gate = gate;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
-    p.H = H; p.dh = dh; p.scale = scale;
-    dim3 grid((max_frames + ABQ - 1) / ABQ, H, B), block(256);
+    p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
+    dim3 grid((max_frames + ABQ - 1) / ABQ, H, B);
     hipStream_t s = (hipStream_t)stream;
-    if (dhp == 64 && np == 1) hipLaunchKernelGGL((attention_kernel<64, SER_MODE_BF16>), grid, block, lds, s, p);
-    else if (dhp == 64) hipLaunchKernelGGL((attention_kernel<64, SER_MODE_FP32X>), grid, block, lds, s, p);
-    else if (np == 1) hipLaunchKernelGGL((attention_kernel<128, SER_MODE_BF16>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((attention_kernel<128, SER_MODE_FP32X>), grid, block, lds, s, p);
-    return ser_check_launch("ser_attention");
+    if (dhp == 64 && np == 1) return launch_attention<64, SER_MODE_BF16>(p, grid, lds, s);
+    if (dhp == 64) return launch_attention<64, SER_MODE_FP32X>(p, grid, lds, s);
+    if (np == 1) return launch_attention<128, SER_MODE_BF16>(p, grid, lds, s);
+    return launch_attention<128, SER_MODE_FP32X>(p, grid, lds, s);
 }

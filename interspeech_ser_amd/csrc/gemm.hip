@@ -1,47 +1,73 @@
-// Matrix-core GEMM with implicit-convolution row map and fused epilogue (ser_gemm).
+// Matrix-core GEMM with implicit-convolution row map and fused epilogues (ser_gemm).
 //
 //   C[m,n] = sum_k A(m,k) * W[n,k]     A: act bf16 (1 or 2 planes), W: bf16 [N][K] (1 or 2 planes)
 //
 // gfx950 design
-//   * 128x128x64 block tile, 256 threads = 4 waves (2x2), 64x64 per wave,
-//     v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the MFMA A operand and the
-//     activation tile as the B operand: the accumulator then holds 4 consecutive output
-//     columns per register quad, and by permuting which weight row sits in which LDS row
-//     each lane ends up owning 16 CONSECUTIVE output columns of one row -> 16-byte
-//     epilogue loads/stores for bias, residual, fp32 and bf16 outputs.
-//   * global -> LDS by global_load_lds_dwordx4 (16 B/lane, no VGPR round trip).  LDS image is
-//     [row][64 bf16] (128-B rows) with 16-B chunk index XOR (row & 7): the DMA destination
-//     stays lane-linear and the swizzle is applied to the per-lane SOURCE address and to
-//     the ds_read_b128 address (both sides or neither).  Verified conflict-free for the
-//     four 16-lane groups of ds_read_b128.
-//   * 2-stage LDS ring (64 KiB -> 2 blocks / CU): loads of tile t+1 are issued before the
-//     MFMAs of tile t, one vmcnt(0)+barrier per K tile.
-//   * FP32X mode runs the same loop over 3 K-segments (hi*hi, lo*hi, hi*lo) into one
-//     accumulator: fp32-grade products on the bf16 pipe.
-//   * blockIdx.x -> tile through a bijective XCD swizzle so the 8 L2s each see a
-//     contiguous run of tiles that share activation panels.
+//   * One kernel template, several tile configurations (host picks per shape):
+//       128x128x64, 4 waves, 2-stage ring, 2 blocks/CU   -- small grids (N = 1024 projections)
+//       256x128x64, 8 waves, 3-stage ring                -- large grids
+//       256x256x64, 8 waves, 2-stage ring                -- largest grids (half the L2->LDS bytes per FLOP)
+//       128x512x32, 8 waves, 3-stage ring, LayerNorm+GELU epilogue over the full 512-wide row
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the MFMA A operand and the activation
+//     tile as the B operand: the accumulator then holds 4 consecutive output columns per register
+//     quad, and by permuting which weight row sits in which LDS row each lane ends up owning
+//     TN*4 CONSECUTIVE output columns of one row -> 16-byte epilogue loads/stores.
+//   * global -> LDS by global_load_lds_dwordx4 (16 B/lane, no VGPR round trip).  The LDS image is
+//     [row][BK bf16] with the 16-B chunk index XOR f(row): the DMA destination stays lane-linear,
+//     the swizzle is applied to the per-lane SOURCE address and to the ds_read_b128 address (both
+//     sides or neither).  f = row & 7 (BK=64) / (row >> 1) & 3 (BK=32): conflict-free for all four
+//     16-lane groups of ds_read_b128 (checked by enumeration).
+//   * S-stage LDS ring with COUNTED s_waitcnt vmcnt(N) and a raw s_barrier: loads of the next S-1
+//     K tiles stay in flight across the barrier (a __syncthreads() would drain them), one barrier
+//     per K tile, s_setprio around the MFMA cluster.
+//   * FP32X mode runs the same loop over 3 K-segments (hi*hi, lo*hi, hi*lo) into one accumulator.
+//   * blockIdx.x -> tile through a bijective XCD swizzle so each of the 8 L2s sees a contiguous run
+//     of tiles that share activation panels.
 #include "ser_common.h"
-
-#define GBM 128
-#define GBN 128
-#define GBK 64
-#define GSTAGE 32768
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void ser_gemm_kernel(const ser_gemm_args p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * GSTAGE];
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N < 0, "add a case");
+}
+
+// WM x WN waves, each TM x TN MFMA tiles of 16x16; BK = K tile; ST = ring stages.
+template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2)
+void ser_gemm_kernel(const ser_gemm_args p) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int CH = BK / 8;                    // 16-byte chunks per LDS row
+    constexpr int ROWB = BK * 2;                  // bytes per LDS row
+    constexpr int RPP = 1024 / ROWB;              // rows per 1-KiB DMA piece (one wave instruction)
+    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+    constexpr int LA = BM / RPP / NW, LW = BN / RPP / NW;       // DMA pieces per wave per K tile
+    constexpr int LPT = LA + LW;
+    constexpr int KS = BK / 32;                   // MFMA k-steps per K tile
     constexpr int NSEG = (MODE == SER_MODE_FP32X) ? 3 : 1;
+    static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile/wave mismatch");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
-    const int ntn = (p.N + GBN - 1) / GBN;
-    const int ntm = (p.M + GBM - 1) / GBM;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int ntm = (p.M + BM - 1) / BM;
     int bid = blockIdx.x;
     {   // bijective XCD remap: blocks with equal (bid & 7) share an L2
         const int nwg = ntm * ntn;
@@ -51,144 +77,306 @@ __global__ __launch_bounds__(256, 2) void ser_gemm_kernel(const ser_gemm_args p)
     }
     const int mt = bid / ntn, nt = bid - mt * ntn;
     const int g = blockIdx.y;
-    const int m0 = mt * GBM, n0 = nt * GBN;
+    const int m0 = mt * BM, n0 = nt * BN;
 
     const unsigned short* Abase = (const unsigned short*)p.A + (int64_t)g * p.a_group_stride;
     const unsigned short* Wbase = (const unsigned short*)p.W + (int64_t)g * p.w_group_stride;
 
-    // ---- per-lane DMA source rows (4 A rows + 4 W rows per k-tile) -------------------
-    const unsigned short* aptr[4];
-    const unsigned short* wptr[4];
+    // ---- per-lane DMA source rows -----------------------------------------------------------
+    const int prow = lane / CH, ppos = lane % CH;
+    const unsigned short* aptr[LA];
+    const unsigned short* wptr[LW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int R = wave * 32 + q * 8 + (lane >> 3);           // LDS row this lane fills
-        const int c = (lane & 7) ^ (R & 7);                       // logical 16-B chunk it must fetch
+    for (int q = 0; q < LA; ++q) {
+        const int R = (q * NW + wave) * RPP + prow;                               // LDS row this lane fills
+        const int f = (BK == 64) ? (R & 7) : ((R >> 1) & 3);
+        const int c = ppos ^ f;                                                   // logical chunk to fetch
         int m = m0 + R;
         m = m < p.M ? m : p.M - 1;
         const int64_t arow = p.a_rowoff ? (int64_t)p.a_rowoff[m] * 8 : (int64_t)m * p.lda;
         aptr[q] = Abase + arow + c * 8;
-        // weight row permutation: LDS row (ni*16 + i) of a wave column holds n = (i>>2)*16 + ni*4 + (i&3)
-        const int i = R & 15, ni = (R >> 4) & 3;
-        int n = n0 + (R & 64) + (i >> 2) * 16 + ni * 4 + (i & 3);
+    }
+#pragma unroll
+    for (int q = 0; q < LW; ++q) {
+        const int R = (q * NW + wave) * RPP + prow;
+        const int f = (BK == 64) ? (R & 7) : ((R >> 1) & 3);
+        const int c = ppos ^ f;
+        // weight-row permutation: LDS row (wcol*TN*16 + ni*16 + i) holds n = wcol*TN*16 + (i>>2)*TN*4 + ni*4 + (i&3)
+        const int wcol = R / (TN * 16), rr = R % (TN * 16);
+        const int i = rr & 15, ni = rr >> 4;
+        int n = n0 + wcol * (TN * 16) + (i >> 2) * (TN * 4) + ni * 4 + (i & 3);
         n = n < p.N ? n : p.N - 1;
         wptr[q] = Wbase + (int64_t)n * p.K + c * 8;
     }
 
-    const int nk = p.K / GBK;
+    const int nk = p.K / BK;
     const int total = nk * NSEG;
-    const int tpc = p.kc ? p.kc / GBK : 0x7fffffff;              // k-tiles per conv chunk
+    const int tpc = p.kc ? p.kc / BK : 0x7fffffff;                                // K tiles per conv chunk
 
-    // running scalar state of the *issue* side
-    int i_kk = 0, i_cc = 0, i_cj = 0, i_seg = 0;
-    auto issue = [&](int stage) {
-        const int64_t koffA = (int64_t)i_cj * p.ldj + (int64_t)i_cc * GBK
+    int i_kk = 0, i_cc = 0, i_cj = 0, i_seg = 0, i_stage = 0;                    // issue-side scalar state
+    auto issue = [&]() {
+        const int64_t koffA = (int64_t)i_cj * p.ldj + (int64_t)i_cc * BK
                             + ((NSEG == 3 && i_seg == 1) ? p.a_plane_stride : 0);
-        const int64_t koffW = (int64_t)i_kk * GBK + ((NSEG == 3 && i_seg == 2) ? p.w_plane_stride : 0);
-        char* dstA = lds + stage * GSTAGE + wave * 4096;
-        char* dstW = dstA + 16384;
+        const int64_t koffW = (int64_t)i_kk * BK + ((NSEG == 3 && i_seg == 2) ? p.w_plane_stride : 0);
+        char* dstA = lds + i_stage * STAGE + wave * 1024;
+        char* dstW = dstA + A_BYTES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[q] + koffA), (lptr_t)(dstA + q * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[q] + koffW), (lptr_t)(dstW + q * 1024), 16, 0, 0);
-        }
+        for (int q = 0; q < LA; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[q] + koffA), (lptr_t)(dstA + q * NW * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < LW; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[q] + koffW), (lptr_t)(dstW + q * NW * 1024), 16, 0, 0);
         ++i_kk; ++i_cc;
         if (i_cc == tpc) { i_cc = 0; ++i_cj; }
         if (i_kk == nk) { i_kk = 0; i_cc = 0; i_cj = 0; ++i_seg; }
+        i_stage = (i_stage + 1 == ST) ? 0 : i_stage + 1;
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[TN][TM];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane fragment read offsets (row & 7 == lane & 7 for every fragment row)
+    // per-lane fragment read offsets; f(row) depends only on the lane because tile bases are multiples of 16
     const int frow = lane & 15, fq = lane >> 4;
-    int offA[2], offW[2];
+    const int fsw = (BK == 64) ? (lane & 7) : ((frow >> 1) & 3);
+    int offA[KS], offW[KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int phys = ((s * 4 + fq) ^ (lane & 7)) << 4;
-        offA[s] = (wm * 64 + frow) * 128 + phys;
-        offW[s] = 16384 + (wn * 64 + frow) * 128 + phys;
+    for (int s = 0; s < KS; ++s) {
+        const int phys = ((s * 4 + fq) ^ fsw) << 4;
+        offA[s] = (wm * TM * 16 + frow) * ROWB + phys;
+        offW[s] = A_BYTES + (wn * TN * 16 + frow) * ROWB + phys;
     }
 
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < total; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < total) issue(stage ^ 1);
-        const char* sb = lds + stage * GSTAGE;
+    constexpr int CPL = TN * 4;
+    const int ncol0 = n0 + wn * (TN * 16) + fq * CPL;                 // within the group
+    const int64_t gcol = (int64_t)g * p.c_group_stride + ncol0;       // in the output matrices
+    float bias[CPL];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], wf[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                af[x] = *(const bf16x8*)(sb + offA[s] + x * 2048);
-                wf[x] = *(const bf16x8*)(sb + offW[s] + x * 2048);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane owns row m, 16 consecutive columns ---------------------------
-    const int ncol0 = n0 + wn * 64 + fq * 16;                     // within the group
-    const int64_t gcol = (int64_t)g * p.c_group_stride + ncol0;   // in the output matrices
-    float bias[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) bias[j] = 0.f;
+    for (int j = 0; j < CPL; ++j) bias[j] = 0.f;
     if (p.bias) {
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4)
+        for (int j4 = 0; j4 < TN; ++j4)
             if (ncol0 + j4 * 4 < p.N) {
                 const f32x4 b = *(const f32x4*)(p.bias + (int64_t)g * p.N + ncol0 + j4 * 4);
                 bias[j4 * 4 + 0] = b[0]; bias[j4 * 4 + 1] = b[1]; bias[j4 * 4 + 2] = b[2]; bias[j4 * 4 + 3] = b[3];
             }
     }
+
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + frow;
-        if (m >= p.M) continue;
-        const int rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
-        const int64_t orow = p.out_rowmap ? (int64_t)p.out_rowmap[m] : (int64_t)m;
+    for (int t = 0; t < ST - 1; ++t)
+        if (t < total) issue();
+
+    int c_stage = 0;
+    for (int kt = 0; kt < total; ++kt) {
+        // tile kt has landed once at most (ST-2) younger tiles are still in flight
+        if (kt + (ST - 2) < total) wait_vmcnt<LPT * (ST - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + ST - 1 < total) issue();           // refills the stage every wave finished reading before the barrier
+        const char* sb = lds + c_stage * STAGE;
+        c_stage = (c_stage + 1 == ST) ? 0 : c_stage + 1;
+        // all k-steps' fragments are requested up front: the LDS reads of step s+1 complete under the
+        // MFMAs of step s (the compiler places counted lgkmcnt waits between the clusters)
+        // (PIPE; the 128x64-per-wave configuration has no registers to spare and loads per step)
+        constexpr bool PIPE = (TM * TN * 4 + KS * (TM + TN) * 4) <= 208;
+        bf16x8 af[KS][TM], wf[KS][TN];
+        if constexpr (PIPE) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            if (ncol0 + ni * 4 >= p.N) continue;
-            float v[4];
+            for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[ni][mi][r] + bias[ni * 4 + r];
-                if (p.act == SER_ACT_GELU) x = gelu_erf(x);
-                v[r] = x;
+                for (int x = 0; x < TM; ++x) af[s][x] = *(const bf16x8*)(sb + offA[s] + x * 16 * ROWB);
+#pragma unroll
+                for (int x = 0; x < TN; ++x) wf[s][x] = *(const bf16x8*)(sb + offW[s] + x * 16 * ROWB);
             }
-            if (p.residual) {
-                const f32x4 rr = *(const f32x4*)(p.residual + (int64_t)rrow * p.ldr + gcol + ni * 4);
-                v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if constexpr (!PIPE) {
+#pragma unroll
+                for (int x = 0; x < TM; ++x) af[s][x] = *(const bf16x8*)(sb + offA[s] + x * 16 * ROWB);
+#pragma unroll
+                for (int x = 0; x < TN; ++x) wf[s][x] = *(const bf16x8*)(sb + offW[s] + x * 16 * ROWB);
             }
-            if (p.out_f32) {
-                f32x4 o = {v[0], v[1], v[2], v[3]};
-                *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4) = o;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][ni], af[s][mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // ---- epilogue: lane owns row m (per mi) and TN*4 consecutive columns ----------------------
+    if constexpr (LNEPI) {
+        // LayerNorm over the full row (N <= BN, one N tile) + GELU, two-pass statistics.
+        // Row partials cross the WN waves of a block row through LDS (the ring is idle now).
+        __syncthreads();
+        float* red = (float*)lds;                                     // [BM][WN]
+        const float invN = 1.0f / (float)p.N;
+        float mean[TM], rstd[TM];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            float s = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = acc[ni][mi][r] + bias[ni * 4 + r];
+                    acc[ni][mi][r] = x;
+                    if (ncol0 + ni * 4 + r < p.N) s += x;
+                }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (fq == 0) red[(wm * TM * 16 + mi * 16 + frow) * WN + wn] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) s += red[(wm * TM * 16 + mi * 16 + frow) * WN + w];
+            mean[mi] = s * invN;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            float s = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[ni][mi][r] - mean[mi];
+                    if (ncol0 + ni * 4 + r < p.N) s += d * d;
+                }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (fq == 0) red[(wm * TM * 16 + mi * 16 + frow) * WN + wn] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) s += red[(wm * TM * 16 + mi * 16 + frow) * WN + w];
+            rstd[mi] = rsqrtf(s * invN + p.ln_eps);
+        }
+        float lg[CPL], lb[CPL];
+#pragma unroll
+        for (int j4 = 0; j4 < TN; ++j4) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (ncol0 + j4 * 4 < p.N) {
+                a = *(const f32x4*)(p.ln_gamma + ncol0 + j4 * 4);
+                b = *(const f32x4*)(p.ln_beta + ncol0 + j4 * 4);
             }
-            if (p.out_act) {
-                store_act4<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4,
-                                 p.out_plane_stride, v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lg[j4 * 4 + r] = a[r]; lb[j4 * 4 + r] = b[r]; }
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * TM * 16 + mi * 16 + frow;
+            if (m >= p.M) continue;
+            const int64_t orow = p.out_rowmap ? (int64_t)p.out_rowmap[m] : (int64_t)m;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                if (ncol0 + ni * 4 >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = (acc[ni][mi][r] - mean[mi]) * rstd[mi] * lg[ni * 4 + r] + lb[ni * 4 + r];
+                    v[r] = (p.act == SER_ACT_GELU) ? gelu_erf(x) : x;
+                }
+                if (p.out_f32) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4) = o;
+                }
+                if (p.out_act)
+                    store_act4<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4,
+                                     p.out_plane_stride, v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * TM * 16 + mi * 16 + frow;
+            if (m >= p.M) continue;
+            const int rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
+            const int64_t orow = p.out_rowmap ? (int64_t)p.out_rowmap[m] : (int64_t)m;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                if (ncol0 + ni * 4 >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[ni][mi][r] + bias[ni * 4 + r];
+                    if (p.act == SER_ACT_GELU) x = gelu_erf(x);
+                    v[r] = x;
+                }
+                if (p.residual) {
+                    const f32x4 rr = *(const f32x4*)(p.residual + (int64_t)rrow * p.ldr + gcol + ni * 4);
+                    v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+                }
+                if (p.out_f32) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4) = o;
+                }
+                if (p.out_act)
+                    store_act4<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4,
+                                     p.out_plane_stride, v[0], v[1], v[2], v[3]);
             }
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3 };
+
+template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI>
+static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int LDS = ST * (BM + BN) * BK * 2;
+    const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
+    dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
+    if (a->mode == SER_MODE_BF16) {
+        auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, SER_MODE_BF16, LNEPI>;
+        static bool ready = false;                 // per instantiation; benign race (idempotent call)
+        if (LDS > 65536 && !ready) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
+            ready = true;
+        }
+        hipLaunchKernelGGL(k, grid, block, LDS, s, *a);
+    } else {
+        auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>;
+        static bool ready = false;
+        if (LDS > 65536 && !ready) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
+            ready = true;
+        }
+        hipLaunchKernelGGL(k, grid, block, LDS, s, *a);
+    }
+    return ser_check_launch("ser_gemm");
+}
+
+static int pick_cfg(const ser_gemm_args* a) {
+    if (a->ln_gamma) return CFG_LN512;
+    if (a->tile_cfg > 0) return a->tile_cfg - 1;
+    // Measured on MI355X (tools/gemm_sweep.py, M = 7984): the simple ring keeps the 128x128 tile
+    // (2 blocks/CU) ahead of 256x128 on every N <= 3072 shape; 256x256 wins once it has >= ~2 full
+    // rounds of blocks (N = 4096, conv layers) because it halves the L2->LDS bytes per FLOP.
+    const long t256x256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
+    if (a->N >= 256 && t256x256 >= 448) return CFG_256x256;
+    return CFG_128x128;
+}
+
 extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W) return ser_fail(-1, "ser_gemm: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return ser_fail(-2, "ser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
-    if (a->K % GBK) return ser_fail(-3, "ser_gemm: K=%d must be a multiple of %d", a->K, GBK);
-    if (a->kc && (a->kc % GBK || a->K % a->kc)) return ser_fail(-4, "ser_gemm: kc=%d must divide K and be a multiple of %d", a->kc, GBK);
+    if (a->K % 64) return ser_fail(-3, "ser_gemm: K=%d must be a multiple of 64", a->K);
+    if (a->kc && (a->kc % 64 || a->K % a->kc)) return ser_fail(-4, "ser_gemm: kc=%d must divide K and be a multiple of 64", a->kc);
     if (a->N % 8) return ser_fail(-5, "ser_gemm: N=%d must be a multiple of 8", a->N);
     if (a->mode != SER_MODE_BF16 && a->mode != SER_MODE_FP32X) return ser_fail(-6, "ser_gemm: bad mode %d", a->mode);
     if (!a->a_rowoff && (a->lda % 8)) return ser_fail(-7, "ser_gemm: lda must be a multiple of 8");
@@ -196,11 +384,17 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (!a->out_f32 && !a->out_act) return ser_fail(-9, "ser_gemm: no output");
     if ((a->ldo_f32 % 4) || (a->ldo_act % 4) || (a->ldr % 4) || (a->c_group_stride % 4))
         return ser_fail(-10, "ser_gemm: output/residual pitches must be multiples of 4");
-    const int ntm = (a->M + GBM - 1) / GBM, ntn = (a->N + GBN - 1) / GBN;
-    dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(256, 1, 1);
-    if (a->mode == SER_MODE_BF16)
-        hipLaunchKernelGGL(ser_gemm_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, *a);
-    else
-        hipLaunchKernelGGL(ser_gemm_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, *a);
-    return ser_check_launch("ser_gemm");
+    if (a->ln_gamma) {
+        if (!a->ln_beta) return ser_fail(-11, "ser_gemm: ln_gamma without ln_beta");
+        if (a->N > 512 || a->groups != 1 || a->residual)
+            return ser_fail(-12, "ser_gemm: the LayerNorm epilogue needs N <= 512, groups == 1, no residual");
+    }
+    if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
+    hipStream_t s = (hipStream_t)stream;
+    switch (pick_cfg(a)) {
+        case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 32, 3, true>(a, s);
+        case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
+        case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
+        default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
+    }
 }

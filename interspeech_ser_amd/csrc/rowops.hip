@@ -50,70 +50,84 @@ extern "C" int ser_wave_norm(const float* wav, const int64_t* sample_offs, int B
 }
 
 // ------------------------------------------------------------------------------- K2
-// Wave per frame: lane owns CPL consecutive channels, weights live in registers.
-template <int CPL, int MODE>
+// Wave per GROUP of frames: consecutive frames overlap in the waveform (stride < kernel), so ONE
+// coalesced 64-sample load serves `rpg` frames (8 for k=10, stride=5); taps are broadcast with
+// v_readlane (wave-uniform index -> scalar operand of the FMA), the next group's samples are
+// fetched before the current group is computed.  Lane owns CPL consecutive channels, weights in
+// registers.  KT = compile-time bound on the kernel width.
+template <int CPL, int KT, int MODE>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const int64_t* __restrict__ soffs,
-                                                    const int32_t* __restrict__ foffs, int B,
+                                                    const int32_t* __restrict__ foffs,
                                                     const float* __restrict__ w, const float* __restrict__ bias,
                                                     const float* __restrict__ lg, const float* __restrict__ lb,
                                                     unsigned short* __restrict__ out, int64_t plane,
-                                                    int k, int stride, int rows) {
+                                                    int k, int stride, int rpg) {
     constexpr int C = CPL * 64;
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;                                    // one grid row per utterance: no row -> utterance search
-    const int row_begin = foffs[b], row_end = foffs[b + 1];
+    const int b = blockIdx.y;                                    // one grid row per utterance
+    const int row_begin = foffs[b], T = foffs[b + 1] - row_begin;
+    const int64_t s0 = soffs[b], nsamp = soffs[b + 1] - s0;
     const int wglobal = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
+    const int ngroups = (T + rpg - 1) / rpg;
     const int c0 = lane * CPL;
-    float wr[CPL][16];
+    float wr[CPL][KT];
     float br[CPL], gr[CPL], be[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wr[i][j] = j < k ? w[(c0 + i) * k + j] : 0.f;
+        for (int j = 0; j < KT; ++j) wr[i][j] = j < k ? w[(c0 + i) * k + j] : 0.f;
         br[i] = bias ? bias[c0 + i] : 0.f;
         gr[i] = lg[c0 + i];
         be[i] = lb[c0 + i];
     }
-    const float* xb = x + soffs[b];
-    for (int row = row_begin + wglobal; row < row_end; row += nwaves) {
-        const int t = row - row_begin;
-        const float* xs = xb + (int64_t)t * stride;
-        const float xv = lane < k ? xs[lane] : 0.f;
-        float v[CPL];
+    const float* xb = x + s0;
+    auto fetch = [&](int g) -> float {
+        const int64_t i = (int64_t)g * rpg * stride + lane;
+        return (g < ngroups && i < nsamp) ? xb[i] : 0.f;
+    };
+    float xv = fetch(wglobal);
+    for (int g = wglobal; g < ngroups; g += nwaves) {
+        const float xn = fetch(g + nwaves);                       // in flight while this group computes
+        const int t0 = g * rpg;
+        const int nrow = (T - t0) < rpg ? (T - t0) : rpg;
+        for (int j = 0; j < nrow; ++j) {
+            float v[CPL];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) v[i] = br[i];
+            for (int i = 0; i < CPL; ++i) v[i] = br[i];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < k) {
-                const float xj = __shfl(xv, j, 64);
+            for (int tap = 0; tap < KT; ++tap) {
+                if (tap < k) {
+                    const float xj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), j * stride + tap));
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) v[i] = fmaf(wr[i][j], xj, v[i]);
+                    for (int i = 0; i < CPL; ++i) v[i] = fmaf(wr[i][tap], xj, v[i]);
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) s += v[i];
+            const float mean = wave_sum(s) * (1.0f / C);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) { const float d = v[i] - mean; q += d * d; }
+            const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) v[i] = gelu_erf((v[i] - mean) * rstd * gr[i] + be[i]);
+            unsigned short* dst = out + (int64_t)(row_begin + t0 + j) * C + c0;
+            if (CPL >= 4) {
+#pragma unroll
+                for (int i = 0; i < CPL; i += 4) store_act4<MODE>(dst + i, plane, v[i], v[i + 1], v[i + 2], v[i + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    unsigned short h, l;
+                    split_bf(v[i], h, l);
+                    dst[i] = h;
+                    if (MODE == SER_MODE_FP32X) dst[plane + i] = l;
+                }
             }
         }
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) s += v[i];
-        const float mean = wave_sum(s) * (1.0f / C);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) { const float d = v[i] - mean; q += d * d; }
-        const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) v[i] = gelu_erf((v[i] - mean) * rstd * gr[i] + be[i]);
-        unsigned short* dst = out + (int64_t)row * C + c0;
-        if (CPL >= 4) {
-#pragma unroll
-            for (int i = 0; i < CPL; i += 4) store_act4<MODE>(dst + i, plane, v[i], v[i + 1], v[i + 2], v[i + 3]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                unsigned short h, l;
-                split_bf(v[i], h, l);
-                dst[i] = h;
-                if (MODE == SER_MODE_FP32X) dst[plane + i] = l;
-            }
-        }
+        xv = xn;
     }
 }
 
@@ -124,21 +138,30 @@ extern "C" int ser_conv0_ln_gelu(const float* wav_norm, const int64_t* sample_of
     if (!wav_norm || !sample_offs || !frame_offs || !w || !ln_g || !ln_b || !out) return ser_fail(-1, "ser_conv0: null pointer");
     if (k < 1 || k > 16 || stride < 1 || total_rows <= 0 || B <= 0) return ser_fail(-2, "ser_conv0: bad k/stride/rows");
     if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_conv0: bad mode");
-    int blocks = ((total_rows + B - 1) / B + 3) / 4;          // average rows per utterance / 4 waves
-    const int cap = (256 * 16 + B - 1) / B;
+    int rpg = (64 - k) / stride + 1;                             // frames served by one 64-sample load
+    if (rpg > 8) rpg = 8;
+    if (rpg < 1) rpg = 1;
+    const int groups_per_utt = ((total_rows + B - 1) / B + rpg - 1) / rpg;
+    int blocks = (groups_per_utt + 3) / 4;
+    const int cap = (256 * 8 + B - 1) / B;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks, B), block(256);
     hipStream_t s = (hipStream_t)stream;
     unsigned short* o = (unsigned short*)out;
-#define LAUNCH(CPL)                                                                                              \
-    do {                                                                                                         \
-        if (mode == SER_MODE_BF16)                                                                               \
-            hipLaunchKernelGGL((conv0_kernel<CPL, SER_MODE_BF16>), grid, block, 0, s, wav_norm, sample_offs,     \
-                               frame_offs, B, w, bias, ln_g, ln_b, o, out_plane_stride, k, stride, total_rows); \
-        else                                                                                                     \
-            hipLaunchKernelGGL((conv0_kernel<CPL, SER_MODE_FP32X>), grid, block, 0, s, wav_norm, sample_offs,    \
-                               frame_offs, B, w, bias, ln_g, ln_b, o, out_plane_stride, k, stride, total_rows); \
+#define LAUNCH2(CPL, KT)                                                                                        \
+    do {                                                                                                        \
+        if (mode == SER_MODE_BF16)                                                                              \
+            hipLaunchKernelGGL((conv0_kernel<CPL, KT, SER_MODE_BF16>), grid, block, 0, s, wav_norm, sample_offs, \
+                               frame_offs, w, bias, ln_g, ln_b, o, out_plane_stride, k, stride, rpg);          \
+        else                                                                                                    \
+            hipLaunchKernelGGL((conv0_kernel<CPL, KT, SER_MODE_FP32X>), grid, block, 0, s, wav_norm, sample_offs, \
+                               frame_offs, w, bias, ln_g, ln_b, o, out_plane_stride, k, stride, rpg);          \
+    } while (0)
+#define LAUNCH(CPL)                                  \
+    do {                                             \
+        if (k <= 10) LAUNCH2(CPL, 10);               \
+        else LAUNCH2(CPL, 16);                       \
     } while (0)
     switch (C) {
         case 64: LAUNCH(1); break;
@@ -148,6 +171,7 @@ extern "C" int ser_conv0_ln_gelu(const float* wav_norm, const int64_t* sample_of
         default: return ser_fail(-4, "ser_conv0: C=%d unsupported (64/128/256/512)", C);
     }
 #undef LAUNCH
+#undef LAUNCH2
     return ser_check_launch("ser_conv0_ln_gelu");
 }
 

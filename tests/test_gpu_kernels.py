@@ -70,6 +70,9 @@ def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
         g.out_plane_stride = out_act.shape[1] * ncols
     rm = kw.get("out_rowmap")
     g.out_rowmap = rm.data_ptr() if rm is not None else None
+    if kw.get("ln") is not None:
+        g.ln_gamma, g.ln_beta, g.ln_eps = kw["ln"][0].data_ptr(), kw["ln"][1].data_ptr(), 1e-5
+    g.tile_cfg = kw.get("tile_cfg", 0)
     L.check(L.lib.ser_gemm(C.byref(g), stream()), "ser_gemm")
     torch.cuda.synchronize()
     return out_f32, out_act
@@ -86,6 +89,42 @@ def test_gemm_integer_exact(L, mode, M, N, K):
     ref = A.double() @ W.double().T
     out, _ = run_gemm(L, to_act(A, mode), to_act(W, mode), M, N, K, mode)
     assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(700, 520, 256), (257, 264, 64), (1030, 128, 640)])
+def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
+    """128x128 / 256x128 / 256x256 block tiles (2- and 3-stage rings) forced through tile_cfg."""
+    g = torch.Generator().manual_seed(M + N + cfg)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    ref = A.double() @ W.double().T + bias.double()
+    out, _ = run_gemm(L, to_act(A, mode), to_act(W, mode), M, N, K, mode, bias=bias.to(DEV), tile_cfg=cfg)
+    assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("M,N,K,bias", [(300, 512, 192, True), (1000, 512, 1536, False), (77, 64, 128, True)])
+def test_gemm_layernorm_gelu_epilogue(L, mode, M, N, K, bias):
+    """Conv-stack epilogue: act(LayerNorm_row(acc + bias)) over the full (<= 512 wide) row."""
+    g = torch.Generator().manual_seed(N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) if bias else None
+    lw, lb = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    Aa, Wa = to_act(A, mode), to_act(W, mode)
+    pre = act_value(Aa).cpu().double() @ act_value(Wa).cpu().double().T
+    if bias:
+        pre = pre + b.double()
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(pre, (N,), lw.double(), lb.double(), 1e-5))
+    out, oact = run_gemm(L, Aa, Wa, M, N, K, mode, bias=b.to(DEV) if bias else None, act=1,
+                         ln=(lw.to(DEV), lb.to(DEV)), want_act=True)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-4, err
+    err_act = (act_value(oact).cpu().double() - ref).abs().max().item()
+    assert err_act < (4e-2 if mode == 1 else 3e-4), err_act
 
 
 @pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 2e-5)])
