@@ -181,15 +181,21 @@ def main():
             "weight_broadcast_s": round(bcast_s, 4),
         }
         if trace:
-            dur_ms = sum(a.elapsed_time(b) for a, b, _ in trace)
-            flops = sum(f for _, _, f in trace)
+            dur_ms = sum(t[0].elapsed_time(t[1]) for t in trace)
+            flops = sum(t[2] for t in trace)
+            algo_bytes = sum(t[3] for t in trace)
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"] if os.path.isfile(pmc) else None
             n = len(trace)
             achieved = flops / (dur_ms * 1e-3) / 1e12
             mult = 3.0 if args.mode == "fp32x" else 1.0
             out["roofline"] = {
                 "kernel": "ser_gemm_kernel (bf16 MFMA implicit-conv GEMM + fused epilogue)",
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, "
+                                "profiles/r01_pmc_traffic.json), same command run eagerly",
+                "algorithmic_bytes_per_launch": round(algo_bytes / n),
                 "launches": n, "avg_launch_us": round(1e3 * dur_ms / n, 2),
                 "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
                 "mfma_products_per_algorithmic_flop": mult,

@@ -40,7 +40,7 @@ struct AttnParams {
     const float* gate;
     unsigned short* out;
     int64_t ldo, out_plane;
-    int H, dh;
+    int H, dh, B, nq;
     int bias_stride;      // floats per shifted bias copy in LDS
     float scale;
 };
@@ -71,10 +71,16 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware decode of the linear block id L: the q-tiles of one (utterance, head) sit at
+    // L, L+8, L+16, ... -> same XCD (blocks are dealt round-robin over the 8 XCDs), close in time,
+    // so K/V are fetched from HBM once and re-read from that XCD's L2 by the other q-tiles.
+    const int L = blockIdx.x;
+    const int bh = (L / (8 * p.nq)) * 8 + (L & 7), qt = (L >> 3) % p.nq;
+    if (bh >= p.H * p.B) return;
+    const int h = bh % p.H, b = bh / p.H;
     const int row0 = p.frame_offs[b];
     const int T = p.frame_offs[b + 1] - row0;
-    const int q0 = blockIdx.x * ABQ;
+    const int q0 = qt * ABQ;
     if (q0 >= T) return;
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
@@ -352,7 +358,8 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     p.frame_offs = frame_offs; p.table = table; p.table_T = table_T; p.gate = gate;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
-    dim3 grid((max_frames + ABQ - 1) / ABQ, H, B);
+    p.B = B; p.nq = (max_frames + ABQ - 1) / ABQ;
+    dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * p.nq), 1, 1);
     hipStream_t s = (hipStream_t)stream;
     if (dhp == 64 && np == 1) return launch_attention<64, SER_MODE_BF16>(p, grid, lds, s);
     if (dhp == 64) return launch_attention<64, SER_MODE_FP32X>(p, grid, lds, s);

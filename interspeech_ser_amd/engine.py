@@ -161,7 +161,12 @@ class _EncoderBase:
         check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
         e1.record()
         # algorithmic FLOPs: 2*M*N*K over real (unpadded) channels, no tile-padding FLOPs
-        self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * (g.K if k_algo is None else k_algo)))
+        k_real = g.K if k_algo is None else k_algo
+        # algorithmic HBM bytes: every operand / result element touched exactly once
+        nbytes = 2.0 * self.planes * (M * k_real * groups + g.N * groups * k_real)
+        nbytes += 4.0 * M * g.N * groups * ((residual is not None) + (out_f32 is not None))
+        nbytes += 2.0 * self.planes * M * g.N * groups * (out_act is not None)
+        self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * k_real, nbytes))
 
     def _layernorm(self, x: torch.Tensor, ldx: int, ln, rows: int, D: int, *, gelu=False, out_f32=None,
                    out_act: Optional[Act] = None, eps=None):
