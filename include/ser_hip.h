@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 2
+#define SER_ABI_VERSION 3
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -103,6 +103,17 @@ typedef struct ser_gemm_args {
     const float*   ln_beta;        /* [N] */
     float          ln_eps;
     int32_t        tile_cfg;       /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile */
+    /* DEFERRED LayerNorm of the A operand (encoder layers: LN -> Linear, HF modeling_wavlm.py:357-358,
+     * 366): the LayerNorm kernel and its HBM round trip disappear.  With W' = W * gamma (folded at load),
+     *   LN(x) W^T + b = rstd_m * (x W'^T - mu_m * colsum(W')_n) + (beta W^T + b)_n
+     * A holds the raw (un-normalised) rows; mu/rstd come from per-row partial sums (sum, sum of squares
+     * per 64-column group) that the PRODUCER of x wrote through stat_out.  bias must hold beta W^T + b. */
+    const float*   ln_stats_in;    /* [M][ln_groups][2] or NULL */
+    int32_t        ln_groups;      /* even */
+    const float*   ln_colsum;      /* [N] */
+    float*         stat_out;       /* [M][stat_groups][2] row partials of the values written, or NULL */
+    int32_t        stat_groups;    /* >= N/64 */
+    int32_t        f32_col_begin;  /* out_f32 receives only columns >= f32_col_begin (stored at n - f32_col_begin) */
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
 
@@ -129,12 +140,16 @@ int ser_wavlm_gate(const void* x_ln, int64_t ldx, int64_t plane_stride, int mode
  * (batch-of-one semantics of preprocess_speech.py:76-81, so no key-padding mask exists).
  * WavLM: HF modeling_wavlm.py:188-241; wav2vec2/HuBERT: modeling_wav2vec2.py:438-548;
  * Whisper: modeling_whisper.py:284-357 (pass scale = dh^-0.5, identical in exact arithmetic).
- * dh in {64, 80, 96, 120, 128}; table/gate NULL for plain attention. */
+ * dh in {64, 80, 96, 120, 128}; table/gate NULL for plain attention.
+ * The WavLM gate is given either as gate[rows,H] (from ser_wavlm_gate) or, fused, as its two
+ * pre-activations per head stored in columns gate_col + 2h, +1 of the qkv matrix (extra output
+ * columns of the packed projection GEMM) together with gru_const[H]. */
 int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
                   const int32_t* frame_offs /*[B+1] device*/, int B, int max_frames,
                   const float* table, int table_T, const float* gate,
                   void* out, int64_t ldo, int64_t out_plane_stride,
-                  int H, int dh, float scale, int mode, void* stream);
+                  int H, int dh, float scale, int mode,
+                  int gate_col, const float* gru_const /*[H]*/, void* stream);
 
 /* K13 Whisper log-mel front end (HF feature_extraction_whisper.py:135-169): packed fp32
  * samples -> [B, n_mels, 3000] fp32 (zero-pad/truncate to 480000, reflect pad, Hann,

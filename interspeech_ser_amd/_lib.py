@@ -17,7 +17,7 @@ MODE_FP32X = 2
 ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -36,6 +36,8 @@ class GemmArgs(C.Structure):
         ("out_act", c_void_p), ("ldo_act", c_i64), ("out_plane_stride", c_i64),
         ("out_rowmap", c_void_p),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("tile_cfg", C.c_int32),
+        ("ln_stats_in", c_void_p), ("ln_groups", C.c_int32), ("ln_colsum", c_void_p),
+        ("stat_out", c_void_p), ("stat_groups", C.c_int32), ("f32_col_begin", C.c_int32),
     ]
 
 
@@ -52,7 +54,7 @@ _SIGNATURES = {
     "ser_wavlm_gate": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                c_int, c_void_p]),
     "ser_attention": (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                              c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_int, c_void_p]),
+                              c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p]),
     "ser_logmel_whisper": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ser_pack_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "ser_mean4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),

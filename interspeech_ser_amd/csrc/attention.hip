@@ -38,6 +38,8 @@ struct AttnParams {
     const float* table;
     int table_T;
     const float* gate;
+    const float* gru_const;
+    int gate_col;
     unsigned short* out;
     int64_t ldo, out_plane;
     int H, dh, B, nq;
@@ -168,7 +170,17 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
             }
     }
     const float c1 = p.scale * LOG2E;
-    const float gq2 = p.gate ? p.gate[(int64_t)(row0 + qc) * p.H + h] * LOG2E : 0.f;
+    float gq2 = 0.f;
+    if (p.gate) {
+        gq2 = p.gate[(int64_t)(row0 + qc) * p.H + h] * LOG2E;
+    } else if (p.gru_const) {
+        // gate pre-activations ride along as two extra columns per head of the packed projection
+        const unsigned short* gp = p.qkv + (int64_t)(row0 + qc) * p.ld + p.gate_col + 2 * h;
+        float pa = bf2f(gp[0]), pb = bf2f(gp[1]);
+        if (NP == 2) { pa += bf2f(gp[p.plane]); pb += bf2f(gp[p.plane + 1]); }
+        const float ga = 1.f / (1.f + __expf(-pa)), gb = 1.f / (1.f + __expf(-pb));
+        gq2 = (ga * (gb * p.gru_const[h] - 1.f) + 2.f) * LOG2E;
+    }
     // aligned bias window: index of key kb (multiple of 4) is kb - qc + T-1 = a + sh with a % 4 == 0
     const int bsh = (T - 1 - qc) & 3;
     const float* bcopy = ldsB + bsh * p.bias_stride + ((T - 1 - qc) - bsh);
@@ -337,13 +349,16 @@ static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStrea
 extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
                              const int32_t* frame_offs, int B, int max_frames, const float* table, int table_T,
                              const float* gate, void* out, int64_t ldo, int64_t out_plane_stride, int H, int dh,
-                             float scale, int mode, void* stream) {
+                             float scale, int mode, int gate_col, const float* gru_const, void* stream) {
     if (!qkv || !frame_offs || !out) return ser_fail(-1, "ser_attention: null pointer");
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
     if ((ld % 8) || (ldo % 4) || (q_col % 8) || (k_col % 8) || (v_col % 8)) return ser_fail(-4, "ser_attention: misaligned pitches/columns");
     if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-5, "ser_attention: bad mode %d", mode);
-    if ((table != nullptr) != (gate != nullptr)) return ser_fail(-6, "ser_attention: table and gate must be given together");
+    if ((table != nullptr) != (gate != nullptr || gru_const != nullptr))
+        return ser_fail(-6, "ser_attention: the bias table needs a gate (gate[] or gate_col + gru_const) and vice versa");
+    if (gate && gru_const) return ser_fail(-9, "ser_attention: give gate[] or gru_const, not both");
+    if (gru_const && (gate_col < 0 || (gate_col % 2))) return ser_fail(-10, "ser_attention: bad gate_col %d", gate_col);
     if (table && table_T < max_frames) return ser_fail(-7, "ser_attention: bias table built for T=%d < max_frames=%d", table_T, max_frames);
     const int dhp = dh <= 64 ? 64 : 128;
     const int np = mode == SER_MODE_FP32X ? 2 : 1;
@@ -356,6 +371,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     p.qkv = (const unsigned short*)qkv; p.ld = ld; p.plane = plane_stride;
     p.q_col = q_col; p.k_col = k_col; p.v_col = v_col;
     p.frame_offs = frame_offs; p.table = table; p.table_T = table_T; p.gate = gate;
+    p.gru_const = gru_const; p.gate_col = gate_col;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
     p.B = B; p.nq = (max_frames + ABQ - 1) / ABQ;

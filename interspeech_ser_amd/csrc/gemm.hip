@@ -164,9 +164,45 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
     }
 
+    // deferred LayerNorm (see ser_hip.h): per-column sum of the gamma-folded weights
+    float csum[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) csum[j] = 0.f;
+    if (p.ln_colsum) {
+#pragma unroll
+        for (int j4 = 0; j4 < TN; ++j4)
+            if (ncol0 + j4 * 4 < p.N) {
+                const f32x4 b = *(const f32x4*)(p.ln_colsum + ncol0 + j4 * 4);
+                csum[j4 * 4 + 0] = b[0]; csum[j4 * 4 + 1] = b[1]; csum[j4 * 4 + 2] = b[2]; csum[j4 * 4 + 3] = b[3];
+            }
+    }
+
 #pragma unroll
     for (int t = 0; t < ST - 1; ++t)
         if (t < total) issue();
+
+    // deferred LayerNorm: row mean / rstd of the A rows from the producer's partial sums, into the
+    // LDS words behind the ring (one row per thread; the loads fly beside the first DMA tiles)
+    float* lnst = (float*)(lds + ST * STAGE);                         // [BM][2]
+    if (p.ln_stats_in) {
+        for (int r = tid; r < BM; r += NT) {
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            const float* ps = p.ln_stats_in + (int64_t)m * p.ln_groups * 2;
+            float s1 = 0.f, s2 = 0.f;
+            for (int gi = 0; gi < p.ln_groups; gi += 2) {              // ln_groups is even: float4 = 2 groups
+                const f32x4 v = *(const f32x4*)(ps + gi * 2);
+                s1 += v[0] + v[2];
+                s2 += v[1] + v[3];
+            }
+            const float invK = 1.0f / (float)p.K;
+            const float mu = s1 * invK;
+            const float var = fmaxf(s2 * invK - mu * mu, 0.f);
+            lnst[2 * r] = mu;
+            lnst[2 * r + 1] = rsqrtf(var + p.ln_eps);
+        }
+        __syncthreads();
+    }
 
     int c_stage = 0;
     for (int kt = 0; kt < total; ++kt) {
@@ -304,13 +340,20 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             if (m >= p.M) continue;
             const int rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
             const int64_t orow = p.out_rowmap ? (int64_t)p.out_rowmap[m] : (int64_t)m;
+            float mu = 0.f, rs = 1.f;
+            if (p.ln_stats_in) {
+                mu = lnst[2 * (wm * TM * 16 + mi * 16 + frow)];
+                rs = lnst[2 * (wm * TM * 16 + mi * 16 + frow) + 1];
+            }
+            float st1 = 0.f, st2 = 0.f;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 if (ncol0 + ni * 4 >= p.N) continue;
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[ni][mi][r] + bias[ni * 4 + r];
+                    // LN(x) W^T = rstd * (x W'^T - mu * colsum(W')) + (beta W^T + b)
+                    float x = fmaf(rs, acc[ni][mi][r] - mu * csum[ni * 4 + r], bias[ni * 4 + r]);
                     if (p.act == SER_ACT_GELU) x = gelu_erf(x);
                     v[r] = x;
                 }
@@ -318,13 +361,26 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     const f32x4 rr = *(const f32x4*)(p.residual + (int64_t)rrow * p.ldr + gcol + ni * 4);
                     v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
                 }
-                if (p.out_f32) {
+                st1 += (v[0] + v[1]) + (v[2] + v[3]);
+                st2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                if (p.out_f32 && ncol0 + ni * 4 >= p.f32_col_begin) {
                     f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4) = o;
+                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4 - p.f32_col_begin) = o;
                 }
                 if (p.out_act)
                     store_act4<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4,
                                      p.out_plane_stride, v[0], v[1], v[2], v[3]);
+            }
+            if (p.stat_out) {
+                // row partials over this wave's 64 columns (deterministic: one slot per 64-column group)
+                st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
+                st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
+                const int cstart = n0 + wn * (TN * 16);
+                const int grp = g * ((p.N + 63) >> 6) + (cstart >> 6);
+                if (fq == 0 && cstart < p.N && grp < p.stat_groups) {
+                    float* d = p.stat_out + ((int64_t)m * p.stat_groups + grp) * 2;
+                    d[0] = st1; d[1] = st2;
+                }
             }
         }
     }
@@ -336,7 +392,7 @@ enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3 };
 template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI>
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int LDS = ST * (BM + BN) * BK * 2;
+    constexpr int LDS = ST * (BM + BN) * BK * 2 + BM * 8;      // ring + [BM][2] row statistics
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     if (a->mode == SER_MODE_BF16) {
@@ -389,6 +445,13 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         if (a->N > 512 || a->groups != 1 || a->residual)
             return ser_fail(-12, "ser_gemm: the LayerNorm epilogue needs N <= 512, groups == 1, no residual");
     }
+    if (a->ln_stats_in) {
+        if (!a->ln_colsum || a->ln_groups < 2 || (a->ln_groups & 1) || a->ln_gamma)
+            return ser_fail(-14, "ser_gemm: deferred LayerNorm needs ln_colsum, an even ln_groups and no fused-LN epilogue");
+    }
+    if (a->stat_out && (a->ln_gamma || a->stat_groups < a->groups * ((a->N + 63) / 64)))
+        return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
+    if (a->f32_col_begin < 0 || (a->f32_col_begin % 4)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 4");
     if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
     hipStream_t s = (hipStream_t)stream;
     switch (pick_cfg(a)) {

@@ -64,6 +64,7 @@ class Linear:
     b: Optional[torch.Tensor]  # [N] fp32
     N: int
     K: int
+    colsum: Optional[torch.Tensor] = None   # [N] fp32: sum_k of the stored (gamma-folded) planes, deferred LayerNorm
 
 
 class HiddenStates:
@@ -119,6 +120,19 @@ class _EncoderBase:
         torch.cuda.current_stream().synchronize()
         return Linear(out, None if b is None else self._dev_f32(b), N, K)
 
+    def _linear_ln(self, w: torch.Tensor, b: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor) -> Linear:
+        """Linear that consumes LayerNorm(x) given the RAW x (deferred LayerNorm, ser_hip.h):
+        store W' = W * gamma, colsum(W') of exactly the bf16 planes the MFMAs will read, and
+        t = beta W^T + b.  Load-time transform, like the weight-norm fold."""
+        w64, g64, be64 = w.detach().double(), ln_w.detach().double(), ln_b.detach().double()
+        lin = self._linear((w64 * g64[None, :]).float(), None)
+        t = w64 @ be64
+        if b is not None:
+            t = t + b.detach().double()
+        lin.b = self._dev_f32(t.float())
+        lin.colsum = lin.w.double().sum(dim=(0, 2)).float().contiguous()
+        return lin
+
     def _new_act(self, rows, cols, zero=False, extra_rows=0) -> Act:
         return Act(rows, cols, self.planes, self.device, zero=zero, extra_rows=extra_rows)
 
@@ -126,7 +140,8 @@ class _EncoderBase:
     def _gemm(self, a: Act, lin: Linear, M: int, *, a_rowoff=None, lda=None, kc=0, ldj=0, groups=1,
               a_group_stride=0, w_group_stride=0, c_group_stride=0, N=None, K=None, act=_lib.ACT_NONE,
               residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
-              out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0):
+              out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0,
+              ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0):
         g = GemmArgs()
         g.A = a.ptr + a_ptr_offset
         g.a_plane_stride = a.plane_stride
@@ -153,6 +168,12 @@ class _EncoderBase:
         if ln is not None:                      # fused LayerNorm over the output row (conv stack)
             g.ln_gamma, g.ln_beta, g.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln_eps)
         g.tile_cfg = tile_cfg
+        if ln_stats is not None:                # deferred LayerNorm of the A rows
+            g.ln_stats_in, g.ln_groups, g.ln_colsum = ln_stats.data_ptr(), ln_groups, lin.colsum.data_ptr()
+            g.ln_eps = float(self.geo.layer_norm_eps)
+        if stat_out is not None:
+            g.stat_out, g.stat_groups = stat_out.data_ptr(), stat_groups
+        g.f32_col_begin = f32_col_begin
         if self.gemm_trace is None:
             check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
             return
@@ -179,11 +200,94 @@ class _EncoderBase:
                                 0 if out_act is None else out_act.plane_stride,
                                 self.mode, rows, D, _stream()), "ser_layernorm")
 
-    def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None):
+    def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
+                   gru_const=None):
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
         check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
                                 max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
-                                H, dh, float(dh ** -0.5), self.mode, _stream()), "ser_attention")
+                                H, dh, float(dh ** -0.5), self.mode, 3 * D, _ptr(gru_const), _stream()),
+              "ser_attention")
+
+    @staticmethod
+    def _stat_groups(n_cols: int, groups: int = 1) -> int:
+        """64-column partial-sum slots a GEMM output of `groups` x `n_cols` columns produces (made even)."""
+        g = groups * ((n_cols + 63) // 64)
+        return g + (g & 1)
+
+    def _run_layers(self, pl, states, first_groups: int, B: int, max_frames: int):
+        """Pre-LN / stable-LN encoder layers with BOTH LayerNorms deferred into the consuming GEMMs:
+        x -> [QKV(+gate) GEMM: LN1 folded] -> attention -> [out GEMM +x -> h] -> [FC1 GEMM: LN2 folded, GELU]
+          -> [FC2 GEMM +h -> next x].  Producers emit the bf16 operand copy and the row partial sums."""
+        geo = self.geo
+        M, D, L = pl["M"], geo.hidden, geo.num_layers
+        wavlm = geo.family == FAMILY_WAVLM
+        gD = self._stat_groups(D)
+        gx = first_groups
+        for i, lay in enumerate(self.layers):
+            x = states[i]
+            last = i + 1 == L
+            nxt = pl["last"] if last else states[i + 1]
+            self._gemm(pl["xa"], lay["qkv"], M, ln_stats=(pl["px0"] if i == 0 else pl["px"]), ln_groups=gx,
+                       out_act=pl["qkv"])
+            if wavlm:
+                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"],
+                                table_T=pl["Tmax"], gru_const=lay["gate_c"])
+            else:
+                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
+            self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D,
+                       out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD)
+            self._gemm(pl["ha"], lay["fc1"], M, ln_stats=pl["ph"], ln_groups=gD, act=_lib.ACT_GELU, out_act=pl["ffn"])
+            if last:
+                self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
+            else:
+                self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D,
+                           out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD)
+            gx = gD
+        self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
+
+    def _layer_weights(self, sd, p: str, a: str, ln1: str, ln2: str, fc1: str, fc2: str, k_bias: bool, gate: bool):
+        """One encoder layer's GEMM operands; LN1 folds into the packed QKV (+gate) projection, LN2 into FC1."""
+        D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
+        kb = sd[a + ".k_proj.bias"] if k_bias else torch.zeros(D)
+        ws = [sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]]
+        bs = [sd[a + ".q_proj.bias"], kb, sd[a + ".v_proj.bias"]]
+        lay = {}
+        if gate:
+            # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in
+            # LN1(x) -> 2H extra output columns of the packed projection; the gate kernel disappears
+            w8, b8 = sd[a + ".gru_rel_pos_linear.weight"].float(), sd[a + ".gru_rel_pos_linear.bias"].float()
+            wa, wb = w8[:4].sum(0), w8[4:].sum(0)
+            wg = torch.zeros(2 * H, D)
+            for h in range(H):
+                wg[2 * h, h * dh:(h + 1) * dh] = wa
+                wg[2 * h + 1, h * dh:(h + 1) * dh] = wb
+            pad = (-2 * H) % 8                                   # GEMM N must stay a multiple of 8
+            ws.append(torch.cat([wg, torch.zeros(pad, D)], 0))
+            bs.append(torch.cat([torch.stack([b8[:4].sum(), b8[4:].sum()]).repeat(H), torch.zeros(pad)]))
+            lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
+        lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"])
+        lay["out"] = self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"])
+        lay["fc1"] = self._linear_ln(sd[fc1 + ".weight"], sd[fc1 + ".bias"], sd[ln2 + ".weight"], sd[ln2 + ".bias"])
+        lay["fc2"] = self._linear(sd[fc2 + ".weight"], sd[fc2 + ".bias"])
+        return lay
+
+    def _layer_buffers(self, pl, M: int, first_groups: int):
+        geo, dev = self.geo, self.device
+        D, Fd = geo.hidden, geo.ffn
+        nqkv = 3 * D + (((2 * geo.heads + 7) // 8) * 8 if geo.family == FAMILY_WAVLM else 0)
+        gD = self._stat_groups(D)
+        pl["xa"] = self._new_act(M, D)
+        pl["ha"] = self._new_act(M, D)
+        # row partial sums (sum, sum^2 per 64-column group).  One buffer per producer layout: a padding
+        # slot (odd group count) is never written and must stay zero.
+        pl["px0"] = torch.zeros((M, first_groups, 2), dtype=torch.float32, device=dev)   # states[0] (stem / pos-conv)
+        pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
+        pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
+        pl["qkv"] = self._new_act(M, nqkv)
+        pl["ctx"] = self._new_act(M, D)
+        pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["ffn"] = self._new_act(M, Fd)
+        pl["last"] = torch.empty((M, D), dtype=torch.float32, device=dev)
 
     def capture(self, packed_wave: torch.Tensor, lengths: Sequence[int]):
         """Record one forward over a fixed batch shape into a hipGraph (via torch's CUDAGraph
@@ -287,20 +391,10 @@ class SpeechEncoder(_EncoderBase):
         self.layers = []
         for i in range(geo.num_layers):
             p = f"encoder.layers.{i}"
-            a = p + ".attention"
-            qkv_w = torch.cat([sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]], 0)
-            qkv_b = torch.cat([sd[a + ".q_proj.bias"], sd[a + ".k_proj.bias"], sd[a + ".v_proj.bias"]], 0)
-            lay = dict(
-                ln1=self._ln_pair(sd, p + ".layer_norm"), qkv=self._linear(qkv_w, qkv_b),
-                out=self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"]),
-                ln2=self._ln_pair(sd, p + ".final_layer_norm"),
-                fc1=self._linear(sd[p + ".feed_forward.intermediate_dense.weight"], sd[p + ".feed_forward.intermediate_dense.bias"]),
-                fc2=self._linear(sd[p + ".feed_forward.output_dense.weight"], sd[p + ".feed_forward.output_dense.bias"]))
-            if geo.family == FAMILY_WAVLM:
-                lay["gate_w"] = self._dev_f32(sd[a + ".gru_rel_pos_linear.weight"])
-                lay["gate_b"] = self._dev_f32(sd[a + ".gru_rel_pos_linear.bias"])
-                lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
-            self.layers.append(lay)
+            self.layers.append(self._layer_weights(
+                sd, p, p + ".attention", p + ".layer_norm", p + ".final_layer_norm",
+                p + ".feed_forward.intermediate_dense", p + ".feed_forward.output_dense",
+                k_bias=True, gate=(geo.family == FAMILY_WAVLM)))
         if geo.family == FAMILY_WAVLM:
             self.rel_embed = self._dev_f32(sd["encoder.layers.0.attention.rel_attn_embed.weight"])
 
@@ -358,14 +452,9 @@ class SpeechEncoder(_EncoderBase):
         pl["proj_f32"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         pl["halo_act"] = self._new_act(pl["halo_rows"], D, zero=True, extra_rows=1)
         pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
-        pl["xn"] = self._new_act(M, D)
-        pl["qkv"] = self._new_act(M, 3 * D)
-        pl["ctx"] = self._new_act(M, D)
-        pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
-        pl["ffn"] = self._new_act(M, Fd)
-        pl["last"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["first_groups"] = self._stat_groups(D // geo.pos_conv_groups, geo.pos_conv_groups)
+        self._layer_buffers(pl, M, pl["first_groups"])
         if geo.family == FAMILY_WAVLM:
-            pl["gate"] = torch.empty((M, geo.heads), dtype=torch.float32, device=dev)
             pl["table"] = torch.empty((geo.heads, 2 * pl["Tmax"] - 1), dtype=torch.float32, device=dev)
             check(lib.ser_wavlm_bias_table(self.rel_embed.data_ptr(), pl["table"].data_ptr(), pl["Tmax"], geo.heads,
                                            geo.num_buckets, geo.max_bucket_distance, _stream()), "ser_wavlm_bias_table")
@@ -428,29 +517,10 @@ class SpeechEncoder(_EncoderBase):
         self._gemm(pl["halo_act"], self.pos, M, a_rowoff=pl["pos_rowoff"], kc=kc, ldj=D, groups=G,
                    a_group_stride=Cg, w_group_stride=Cg * geo.pos_conv_kernel * kc, c_group_stride=Cg,
                    N=Cg, K=geo.pos_conv_kernel * kc, act=_lib.ACT_GELU, residual=pl["proj_f32"], ldr=D,
-                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg)
-        # a11/a12: stable-LayerNorm encoder layers
-        L = geo.num_layers
-        wavlm = geo.family == FAMILY_WAVLM
-        for i, lay in enumerate(self.layers):
-            x = states[i]
-            nxt = states[i + 1] if i + 1 < L else pl["last"]
-            self._layernorm(x, D, lay["ln1"], M, D, out_act=pl["xn"])
-            if wavlm:
-                check(lib.ser_wavlm_gate(pl["xn"].ptr, D, pl["xn"].plane_stride, self.mode, lay["gate_w"].data_ptr(),
-                                         lay["gate_b"].data_ptr(), lay["gate_c"].data_ptr(), pl["gate"].data_ptr(),
-                                         M, geo.heads, geo.head_dim, st), "ser_wavlm_gate")
-            self._gemm(pl["xn"], lay["qkv"], M, out_act=pl["qkv"])
-            if wavlm:
-                self._attention(pl["qkv"], pl["frame_offs"], B, pl["Tmax"], pl["ctx"], table=pl["table"],
-                                table_T=pl["Tmax"], gate=pl["gate"])
-            else:
-                self._attention(pl["qkv"], pl["frame_offs"], B, pl["Tmax"], pl["ctx"])
-            self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D)
-            self._layernorm(pl["h"], D, lay["ln2"], M, D, out_act=pl["xn"])
-            self._gemm(pl["xn"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
-            self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
-        self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
+                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg,
+                   out_act=pl["xa"], stat_out=pl["px0"], stat_groups=pl["first_groups"])
+        # a11/a12: stable-LayerNorm encoder layers (LayerNorms deferred into the GEMMs)
+        self._run_layers(pl, states, pl["first_groups"], B, pl["Tmax"])
         return HiddenStates(states, pl["frame_offs_host"])
 
 
@@ -477,15 +547,9 @@ class WhisperEncoder(_EncoderBase):
         self.layers = []
         for i in range(geo.num_layers):
             p = f"encoder.layers.{i}"
-            a = p + ".self_attn"
-            qkv_w = torch.cat([sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]], 0)
-            qkv_b = torch.cat([sd[a + ".q_proj.bias"], torch.zeros(D), sd[a + ".v_proj.bias"]], 0)   # k_proj has no bias
-            self.layers.append(dict(
-                ln1=self._ln_pair(sd, p + ".self_attn_layer_norm"), qkv=self._linear(qkv_w, qkv_b),
-                out=self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"]),
-                ln2=self._ln_pair(sd, p + ".final_layer_norm"),
-                fc1=self._linear(sd[p + ".fc1.weight"], sd[p + ".fc1.bias"]),
-                fc2=self._linear(sd[p + ".fc2.weight"], sd[p + ".fc2.bias"])))
+            self.layers.append(self._layer_weights(
+                sd, p, p + ".self_attn", p + ".self_attn_layer_norm", p + ".final_layer_norm",
+                p + ".fc1", p + ".fc2", k_bias=False, gate=False))        # k_proj has no bias
 
     def _plan(self, lengths, slot: int = 0):
         key_full = (slot,) + tuple(int(n) for n in lengths)
@@ -516,12 +580,8 @@ class WhisperEncoder(_EncoderBase):
         pl["frame_offs_host"] = [int(b * T2) for b in range(B + 1)]
         pl["frame_offs"] = torch.tensor(pl["frame_offs_host"], dtype=torch.int32, device=dev)
         pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
-        pl["xn"] = self._new_act(M, D)
-        pl["qkv"] = self._new_act(M, 3 * D)
-        pl["ctx"] = self._new_act(M, D)
-        pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
-        pl["ffn"] = self._new_act(M, Fd)
-        pl["last"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["first_groups"] = self._stat_groups(D)
+        self._layer_buffers(pl, M, pl["first_groups"])
         if len(self._cache) >= 2:
             self._cache.pop(next(iter(self._cache)))
         self._cache[key_full] = pl
@@ -557,19 +617,9 @@ class WhisperEncoder(_EncoderBase):
                    out_rowmap=pl["c1_rowmap"])
         states = pl["states"]
         self._gemm(pl["c1_act"], self.conv2, M, a_rowoff=pl["c2_rowoff"], act=_lib.ACT_GELU, residual=self.pos_emb,
-                   ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D)
-        L = geo.num_layers
-        for i, lay in enumerate(self.layers):
-            x = states[i]
-            nxt = states[i + 1] if i + 1 < L else pl["last"]
-            self._layernorm(x, D, lay["ln1"], M, D, out_act=pl["xn"])
-            self._gemm(pl["xn"], lay["qkv"], M, out_act=pl["qkv"])
-            self._attention(pl["qkv"], pl["frame_offs"], B, T2, pl["ctx"])
-            self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D)
-            self._layernorm(pl["h"], D, lay["ln2"], M, D, out_act=pl["xn"])
-            self._gemm(pl["xn"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
-            self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
-        self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
+                   ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D,
+                   out_act=pl["xa"], stat_out=pl["px0"], stat_groups=pl["first_groups"])
+        self._run_layers(pl, states, pl["first_groups"], B, T2)
         return HiddenStates(states, pl["frame_offs_host"])
 
 

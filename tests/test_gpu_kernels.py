@@ -72,6 +72,11 @@ def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
     g.out_rowmap = rm.data_ptr() if rm is not None else None
     if kw.get("ln") is not None:
         g.ln_gamma, g.ln_beta, g.ln_eps = kw["ln"][0].data_ptr(), kw["ln"][1].data_ptr(), 1e-5
+    if kw.get("ln_stats") is not None:
+        g.ln_stats_in, g.ln_groups, g.ln_colsum = kw["ln_stats"].data_ptr(), kw["ln_groups"], kw["ln_colsum"].data_ptr()
+        g.ln_eps = 1e-5
+    if kw.get("stat_out") is not None:
+        g.stat_out, g.stat_groups = kw["stat_out"].data_ptr(), kw["stat_out"].shape[1]
     g.tile_cfg = kw.get("tile_cfg", 0)
     L.check(L.lib.ser_gemm(C.byref(g), stream()), "ser_gemm")
     torch.cuda.synchronize()
@@ -125,6 +130,37 @@ def test_gemm_layernorm_gelu_epilogue(L, mode, M, N, K, bias):
     assert err < 2e-4, err
     err_act = (act_value(oact).cpu().double() - ref).abs().max().item()
     assert err_act < (4e-2 if mode == 1 else 3e-4), err_act
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_gemm_row_stats_and_deferred_layernorm(L, mode, cfg):
+    """Producer GEMM writes x (fp32 + act) and per-64-column (sum, sum^2) partials; the consumer GEMM
+    applies LayerNorm(x) W^T + b as rstd*(x W'^T - mu*colsum(W')) + (beta W^T + b) from the RAW x."""
+    M, D, N2 = 333, 320, 200
+    g = torch.Generator().manual_seed(77 + cfg)
+    A0 = torch.randn(M, 128, generator=g)
+    W0 = torch.randn(D, 128, generator=g) / math.sqrt(128)
+    res = torch.randn(M, D, generator=g) * 2 + 0.7                       # non-zero row mean on purpose
+    G = (D + 63) // 64
+    G += G & 1
+    stat = torch.zeros(M, G, 2, device=DEV)
+    x_f32, x_act = run_gemm(L, to_act(A0, mode), to_act(W0, mode), M, D, 128, mode, residual=res.to(DEV), ldr=D,
+                            want_act=True, stat_out=stat, tile_cfg=cfg)
+    x = x_f32.cpu().double()
+    st = stat.cpu().double().sum(1)
+    assert (st[:, 0] - x.sum(1)).abs().max() < 1e-3 and (st[:, 1] - (x * x).sum(1)).abs().max() < 2e-2
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    W = torch.randn(N2, D, generator=g) / math.sqrt(D)
+    b = torch.randn(N2, generator=g)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (D,), gamma.double(), beta.double(), 1e-5),
+                                     W.double(), b.double())
+    Wp = to_act((W.double() * gamma.double()[None, :]).float(), mode)
+    colsum = act_value(Wp).double().sum(1).float().contiguous()
+    t = (W.double() @ beta.double() + b.double()).float().to(DEV)
+    out, _ = run_gemm(L, x_act, Wp, M, N2, D, mode, bias=t, ln_stats=stat, ln_groups=G, ln_colsum=colsum, tile_cfg=cfg)
+    err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (3e-2 if mode == 1 else 5e-5), err
 
 
 @pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 2e-5)])
@@ -386,7 +422,43 @@ def test_attention(L, mode, dh, H, bias):
     gd = gate.to(DEV) if bias else None
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
                                 td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
-                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, stream()))
+                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, stream()))
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < (3e-2 if mode == 1 else 1e-4), err
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_fused_gate_columns(L, mode):
+    """WavLM gate from its two pre-activation columns per head inside the packed projection matrix."""
+    Ts, H, dh = [90, 200], 2, 64
+    D, M = H * dh, sum(Ts)
+    g = torch.Generator().manual_seed(5)
+    ld = 3 * D + 2 * H + 4                                      # +4: pitch stays a multiple of 8
+    qkv = torch.randn(M, ld, generator=g)
+    qkv[:, : 2 * D] *= 1.5
+    qa = to_act(qkv, mode)
+    qv = act_value(qa).cpu().double()
+    Tmax = max(Ts)
+    table = torch.randn(H, 2 * Tmax - 1, generator=g)
+    cst = torch.randn(H, generator=g) + 1.0
+    pre = qv[:, 3 * D: 3 * D + 2 * H].view(M, H, 2)
+    a, bsg = torch.sigmoid(pre[..., 0]), torch.sigmoid(pre[..., 1])
+    gate = a * (bsg * cst.double()[None, :] - 1.0) + 2.0
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    ref = torch.empty(M, D, dtype=torch.float64)
+    for b, T in enumerate(Ts):
+        blk = qv[offs[b]:offs[b + 1]]
+        q, k, v = (blk[:, i * D:(i + 1) * D].view(T, H, dh).permute(1, 0, 2) for i in range(3))
+        c = Tmax - 1
+        o = attention_reference(q, k, v, dh ** -0.5, table[:, c - (T - 1): c + T].double(), gate[offs[b]:offs[b + 1]])
+        ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
+    planes = 2 if mode == 2 else 1
+    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    td, cd = table.to(DEV), cst.to(DEV)
+    L.check(L.lib.ser_attention(qa.data_ptr(), ld, M * ld, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax, td.data_ptr(), Tmax,
+                                None, out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 3 * D, cd.data_ptr(), stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < (3e-2 if mode == 1 else 1e-4), err
@@ -405,7 +477,7 @@ def test_attention_online_softmax_rescale(L):
     out = torch.zeros(2, T, dh, dtype=torch.bfloat16, device=DEV)
     foffs = torch.tensor([0, T], dtype=torch.int32, device=DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * dh, T * 3 * dh, 0, dh, 2 * dh, foffs.data_ptr(), 1, T, None, 0, None,
-                                out.data_ptr(), dh, T * dh, H, dh, dh ** -0.5, 2, stream()))
+                                out.data_ptr(), dh, T * dh, H, dh, dh ** -0.5, 2, 0, None, stream()))
     torch.cuda.synchronize()
     assert (act_value(out).cpu().double() - ref).abs().max().item() < 1e-4
 
