@@ -44,6 +44,14 @@ def algorithmic_gflop_per_utt(geo, num_samples):
     return (fl + geo.num_layers * per_layer) / 1e9
 
 
+def whisper_gflop_per_utt(geo):
+    """Whisper encoder on the fixed 30 s window: stem convs + L pre-LN layers (2273.9 GF for large-v3)."""
+    T, D, F = geo.max_source_positions, geo.hidden, geo.ffn
+    stem = 2.0 * 3000 * D * geo.n_mels * 3 + 2.0 * T * D * D * 3
+    per_layer = 2.0 * T * D * 3 * D + 2.0 * T * D * D + 2 * (2.0 * T * T * D) + 2 * (2.0 * T * D * F)
+    return (stem + geo.num_layers * per_layer) / 1e9
+
+
 def synth_batch(batch, num_samples, seed):
     g = torch.Generator().manual_seed(seed)
     return [(0.1 * torch.randn(num_samples, generator=g)).numpy() for _ in range(batch)]
@@ -114,8 +122,7 @@ def main():
     geo = C.geometry_for(args.ssl_type)
     if args.layers:
         geo = C.with_layers(geo, args.layers)
-    if geo.family == C.FAMILY_WHISPER:
-        raise SystemExit("bench.py measures the speech families; see DESIGN.md for the Whisper figures")
+    whisper = geo.family == C.FAMILY_WHISPER
     num_samples = int(round(args.seconds * 16000))
 
     sd, bcast_s = broadcast_weights(geo, 0, rank)
@@ -165,16 +172,17 @@ def main():
     if rank == 0:
         total_utts = args.batch * args.steps * world
         value = total_utts / elapsed
-        gf_utt = algorithmic_gflop_per_utt(geo, num_samples)
+        gf_utt = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
         out = {
-            "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract",
+            "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract" if geo is C.WAVLM_LARGE and abs(args.seconds - 10) < 1e-6
+                      else f"utterances/sec ({args.seconds:.0f} s @16 kHz) {geo.name} embed extract",
             "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.mode == "bf16" else "bf16x3 (fp32-grade split)", "data": "synthetic",
             "config": {"workload": f"{geo.name} embed extract, batch={args.batch} x {args.seconds:.0f} s @16 kHz per GPU, "
                                    f"all {geo.num_layers + 1} hidden states to HBM, mode={args.mode}",
-                       "frames_per_utt": geo.frames_for(num_samples), "gflop_per_utt": round(gf_utt, 1),
+                       "frames_per_utt": geo.max_source_positions if whisper else geo.frames_for(num_samples), "gflop_per_utt": round(gf_utt, 1),
                        "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
             "achieved_tflops_whole_path": round(value * gf_utt / 1e3 / world, 1),
             "launch": "eager" if args.no_graph else f"hipGraph replay, {args.micro} concurrent utterance group(s)",
@@ -202,7 +210,7 @@ def main():
                 "gemm_ms_per_step": round(dur_ms / args.steps, 3),
                 "measured": "HIP events around every ser_gemm launch, eager pass of the same K steps right after the timed region",
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not whisper:
             from interspeech_ser_amd.weights import synthetic_state_dict
             out["cpu_baseline"] = cpu_baseline(geo, sd, num_samples)
         print(json.dumps(out), flush=True)

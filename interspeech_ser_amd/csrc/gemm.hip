@@ -189,12 +189,14 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             int m = m0 + r;
             m = m < p.M ? m : p.M - 1;
             const float* ps = p.ln_stats_in + (int64_t)m * p.ln_groups * 2;
+            // all partials are requested before any is consumed (up to 32 groups = 16 loads in flight)
+            f32x4 pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                pv[u] = (2 * u < p.ln_groups) ? *(const f32x4*)(ps + 4 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
             float s1 = 0.f, s2 = 0.f;
-            for (int gi = 0; gi < p.ln_groups; gi += 2) {              // ln_groups is even: float4 = 2 groups
-                const f32x4 v = *(const f32x4*)(ps + gi * 2);
-                s1 += v[0] + v[2];
-                s2 += v[1] + v[3];
-            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { s1 += pv[u][0] + pv[u][2]; s2 += pv[u][1] + pv[u][3]; }
             const float invK = 1.0f / (float)p.K;
             const float mu = s1 * invK;
             const float var = fmaxf(s2 * invK - mu * mu, 0.f);
@@ -446,8 +448,8 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
             return ser_fail(-12, "ser_gemm: the LayerNorm epilogue needs N <= 512, groups == 1, no residual");
     }
     if (a->ln_stats_in) {
-        if (!a->ln_colsum || a->ln_groups < 2 || (a->ln_groups & 1) || a->ln_gamma)
-            return ser_fail(-14, "ser_gemm: deferred LayerNorm needs ln_colsum, an even ln_groups and no fused-LN epilogue");
+        if (!a->ln_colsum || a->ln_groups < 2 || a->ln_groups > 32 || (a->ln_groups & 1) || a->ln_gamma)
+            return ser_fail(-14, "ser_gemm: deferred LayerNorm needs ln_colsum, an even ln_groups in [2,32] and no fused-LN epilogue");
     }
     if (a->stat_out && (a->ln_gamma || a->stat_groups < a->groups * ((a->N + 63) / 64)))
         return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
