@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 3
+#define SER_ABI_VERSION 4
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -114,6 +114,11 @@ typedef struct ser_gemm_args {
     float*         stat_out;       /* [M][stat_groups][2] row partials of the values written, or NULL */
     int32_t        stat_groups;    /* >= N/64 */
     int32_t        f32_col_begin;  /* out_f32 receives only columns >= f32_col_begin (stored at n - f32_col_begin) */
+    /* columns n < col_scale_end are multiplied by col_scale after bias (before act): the packed QKV projection
+     * scales q by dh^-0.5 (what HF does before the product, modeling_whisper.py:309) times log2(e), so the
+     * attention kernel's softmax runs in the exp2 domain with no per-score multiply. */
+    float          col_scale;
+    int32_t        col_scale_end;  /* multiple of 4; 0 = no scaling */
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
 
@@ -140,6 +145,7 @@ int ser_wavlm_gate(const void* x_ln, int64_t ldx, int64_t plane_stride, int mode
  * (batch-of-one semantics of preprocess_speech.py:76-81, so no key-padding mask exists).
  * WavLM: HF modeling_wavlm.py:188-241; wav2vec2/HuBERT: modeling_wav2vec2.py:438-548;
  * Whisper: modeling_whisper.py:284-357 (pass scale = dh^-0.5, identical in exact arithmetic).
+ * scale <= 0 means q is PRE-SCALED by dh^-0.5 * log2(e) (ser_gemm col_scale): scores are used as exp2 exponents.
  * dh in {64, 80, 96, 120, 128}; table/gate NULL for plain attention.
  * The WavLM gate is given either as gate[rows,H] (from ser_wavlm_gate) or, fused, as its two
  * pre-activations per head stored in columns gate_col + 2h, +1 of the qkv matrix (extra output

@@ -17,7 +17,7 @@ MODE_FP32X = 2
 ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("tile_cfg", C.c_int32),
         ("ln_stats_in", c_void_p), ("ln_groups", C.c_int32), ("ln_colsum", c_void_p),
         ("stat_out", c_void_p), ("stat_groups", C.c_int32), ("f32_col_begin", C.c_int32),
+        ("col_scale", c_float), ("col_scale_end", C.c_int32),
     ]
 
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
     return DHP == 64 ? (unit ^ ((key >> 1) & 1)) : (unit ^ (key & 3));
 }
 
-template <int DHP, int MODE>
+template <int DHP, int MODE, bool PRE>
 __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2) void attention_kernel(const AttnParams p) {
     constexpr int NP = (MODE == SER_MODE_FP32X) ? 2 : 1;
     constexpr int RS = DHP * 2;                 // LDS row bytes
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
 
     // ---- staging helpers: thread owns chunks c = tid + i*256 of the [64 keys][CPR] tile --------
     u32x4 stg[NP][2][NCH];
-    auto stage_load = [&](int kt) {
+    const bool padded = (dh != DHP);
+    auto stage_load = [&](int kt, bool masked) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * 256;
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
             for (int pl = 0; pl < NP; ++pl) {
                 u32x4 kv = *(const u32x4*)(src + p.k_col + pl * p.plane);
                 u32x4 vv = *(const u32x4*)(src + p.v_col + pl * p.plane);
+                if (masked) {                                    // wave-uniform: only ragged tiles / padded head dims
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { kv[e] &= keep; vv[e] &= keep; }
+                    for (int e = 0; e < 4; ++e) { kv[e] &= keep; vv[e] &= keep; }
+                }
                 stg[pl][0][i] = kv;
                 stg[pl][1][i] = vv;
             }
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
         }
     };
 
-    stage_load(0);
+    const int nfull = (T & (ABKV - 1)) ? nkt - 1 : nkt;          // tiles without key padding
+    stage_load(0, padded || nfull == 0);
 
     // ---- this head's bias row, 4 shifted copies: copy c [j] = table[h][(table_T-T) + j + c] -------
     if (p.table) {
@@ -200,14 +204,26 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
         const int cur = DB ? (kt & 1) : 0;
         const char* ldsK = smem + cur * BUF;
         const char* ldsV = ldsK + NP * TILE;
-        if (DB && kt + 1 < nkt) stage_load(kt + 1);                 // issue early: lands under the MFMAs below
+        if (DB && kt + 1 < nkt) stage_load(kt + 1, padded || kt + 1 >= nfull);   // issue early: lands under the MFMAs below
 
         // ---- S^T = K Q^T  (rows = keys in registers, col = query on the lane)
+        // PRE (q pre-scaled by dh^-0.5*log2e in the projection epilogue): the accumulators START at the
+        // gated bias, so the MFMA chain delivers finished exp2-domain scores (no per-score multiply/add).
         f32x16 st[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            if (PRE && p.table) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
+                    const f32x4 bv = *(const f32x4*)(bcopy + kb);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = gq2 * bv[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+            }
             const int key = sub * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -230,10 +246,10 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.table) bv = *(const f32x4*)(bcopy + kb);
+                if (!PRE && p.table) bv = *(const f32x4*)(bcopy + kb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = fmaf(st[sub][4 * g4 + r], c1, gq2 * bv[r]);
+                    float v = PRE ? st[sub][4 * g4 + r] : fmaf(st[sub][4 * g4 + r], c1, gq2 * bv[r]);
                     if (RAGGED) v = (kb + r < T) ? v : -INFINITY;
                     st[sub][4 * g4 + r] = v;
                     mloc = fmaxf(mloc, v);
@@ -306,14 +322,13 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
                 __syncthreads();
             } else {
                 __syncthreads();                                     // everyone done with the single buffer
-                stage_load(kt + 1);
+                stage_load(kt + 1, padded || kt + 1 >= nfull);
                 stage_write(0);
                 __syncthreads();
             }
         }
     };
     // the key-padding select exists only in the last tile of a ragged utterance
-    const int nfull = (T & (ABKV - 1)) ? nkt - 1 : nkt;
     for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
     if (nfull < nkt) tile(nkt - 1, std::true_type{});
 
@@ -333,9 +348,9 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
     }
 }
 
-template <int DHP, int MODE>
+template <int DHP, int MODE, bool PRE>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE>;
+    auto k = attention_kernel<DHP, MODE, PRE>;
     static bool ready = false;
     if (lds > 65536 && !ready) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -377,8 +392,11 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     p.B = B; p.nq = (max_frames + ABQ - 1) / ABQ;
     dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * p.nq), 1, 1);
     hipStream_t s = (hipStream_t)stream;
-    if (dhp == 64 && np == 1) return launch_attention<64, SER_MODE_BF16>(p, grid, lds, s);
-    if (dhp == 64) return launch_attention<64, SER_MODE_FP32X>(p, grid, lds, s);
-    if (np == 1) return launch_attention<128, SER_MODE_BF16>(p, grid, lds, s);
-    return launch_attention<128, SER_MODE_FP32X>(p, grid, lds, s);
+    const bool pre = scale <= 0.f;
+#define SER_ATTN(D_, M_) (pre ? launch_attention<D_, M_, true>(p, grid, lds, s) : launch_attention<D_, M_, false>(p, grid, lds, s))
+    if (dhp == 64 && np == 1) return SER_ATTN(64, SER_MODE_BF16);
+    if (dhp == 64) return SER_ATTN(64, SER_MODE_FP32X);
+    if (np == 1) return SER_ATTN(128, SER_MODE_BF16);
+    return SER_ATTN(128, SER_MODE_FP32X);
+#undef SER_ATTN
 }

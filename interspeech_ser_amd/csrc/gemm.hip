@@ -356,6 +356,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 for (int r = 0; r < 4; ++r) {
                     // LN(x) W^T = rstd * (x W'^T - mu * colsum(W')) + (beta W^T + b)
                     float x = fmaf(rs, acc[ni][mi][r] - mu * csum[ni * 4 + r], bias[ni * 4 + r]);
+                    if (ncol0 + ni * 4 < p.col_scale_end) x *= p.col_scale;        // e.g. q *= dh^-0.5 * log2(e)
                     if (p.act == SER_ACT_GELU) x = gelu_erf(x);
                     v[r] = x;
                 }
@@ -453,6 +454,7 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     }
     if (a->stat_out && (a->ln_gamma || a->stat_groups < a->groups * ((a->N + 63) / 64)))
         return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
+    if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 4)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 4");
     if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
     hipStream_t s = (hipStream_t)stream;

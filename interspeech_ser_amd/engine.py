@@ -141,7 +141,8 @@ class _EncoderBase:
               a_group_stride=0, w_group_stride=0, c_group_stride=0, N=None, K=None, act=_lib.ACT_NONE,
               residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
               out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0,
-              ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0):
+              ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0,
+              col_scale=1.0, col_scale_end=0):
         g = GemmArgs()
         g.A = a.ptr + a_ptr_offset
         g.a_plane_stride = a.plane_stride
@@ -174,6 +175,7 @@ class _EncoderBase:
         if stat_out is not None:
             g.stat_out, g.stat_groups = stat_out.data_ptr(), stat_groups
         g.f32_col_begin = f32_col_begin
+        g.col_scale, g.col_scale_end = float(col_scale), int(col_scale_end)
         if self.gemm_trace is None:
             check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
             return
@@ -205,7 +207,7 @@ class _EncoderBase:
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
         check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
                                 max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
-                                H, dh, float(dh ** -0.5), self.mode, 3 * D, _ptr(gru_const), _stream()),
+                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _stream()),   # q is pre-scaled
               "ser_attention")
 
     @staticmethod
@@ -227,8 +229,9 @@ class _EncoderBase:
             x = states[i]
             last = i + 1 == L
             nxt = pl["last"] if last else states[i + 1]
+            # q columns leave the projection already multiplied by dh^-0.5 * log2(e)
             self._gemm(pl["xa"], lay["qkv"], M, ln_stats=(pl["px0"] if i == 0 else pl["px"]), ln_groups=gx,
-                       out_act=pl["qkv"])
+                       out_act=pl["qkv"], col_scale=geo.head_dim ** -0.5 * 1.4426950408889634, col_scale_end=D)
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"],
                                 table_T=pl["Tmax"], gru_const=lay["gate_c"])

@@ -464,6 +464,64 @@ def test_attention_fused_gate_columns(L, mode):
     assert err < (3e-2 if mode == 1 else 1e-4), err
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dh,bias", [(64, True), (64, False), (120, False)])
+def test_attention_prescaled_q(L, mode, dh, bias):
+    """scale <= 0: q arrives multiplied by dh^-0.5*log2(e) (projection epilogue); scores are exp2 exponents and,
+    with a bias table, the MFMA accumulators start at gate*bias."""
+    Ts, H = [150, 64, 333], 2
+    D, M = H * dh, sum(Ts)
+    g = torch.Generator().manual_seed(dh)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    qkv[:, : 2 * D] *= 1.5
+    pre = qkv.clone()
+    pre[:, :D] *= dh ** -0.5 * 1.4426950408889634
+    qa = to_act(pre, mode)
+    qv = act_value(qa).cpu().double()
+    qv[:, :D] /= dh ** -0.5 * 1.4426950408889634               # reference sees the un-scaled (already rounded) q
+    Tmax = max(Ts)
+    table = torch.randn(H, 2 * Tmax - 1, generator=g) if bias else None
+    gate = torch.rand(M, H, generator=g) * 2 if bias else None
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    ref = torch.empty(M, D, dtype=torch.float64)
+    for b, T in enumerate(Ts):
+        blk = qv[offs[b]:offs[b + 1]]
+        q, k, v = (blk[:, i * D:(i + 1) * D].view(T, H, dh).permute(1, 0, 2) for i in range(3))
+        c = Tmax - 1
+        o = attention_reference(q, k, v, dh ** -0.5, table[:, c - (T - 1): c + T].double() if bias else None,
+                                gate[offs[b]:offs[b + 1]].double() if bias else None)
+        ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
+    planes = 2 if mode == 2 else 1
+    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    td = table.to(DEV) if bias else None
+    gd = gate.to(DEV) if bias else None
+    L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
+                                td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
+                                out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, stream()))
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < (3e-2 if mode == 1 else 1e-4), err
+
+
+def test_gemm_column_scale(L):
+    M, N, K = 130, 96, 64
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float()
+    gargs = dict(bias=torch.ones(N).to(DEV))
+    ref = (A @ W.T + 1.0)
+    ref[:, :32] *= 0.5
+    g2 = L.GemmArgs()
+    out = torch.empty(M, N, device=DEV)
+    Aa, Wa, b = to_act(A, 1), to_act(W, 1), torch.ones(N, device=DEV)
+    g2.A, g2.lda, g2.W, g2.M, g2.N, g2.K, g2.groups, g2.mode = Aa.data_ptr(), K, Wa.data_ptr(), M, N, K, 1, 1
+    g2.bias, g2.out_f32, g2.ldo_f32, g2.col_scale, g2.col_scale_end = b.data_ptr(), out.data_ptr(), N, 0.5, 32
+    L.check(L.lib.ser_gemm(C.byref(g2), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+
+
 def test_attention_online_softmax_rescale(L):
     """A key in a late tile dominates: forces the running-max rescale branch (one spike per head)."""
     T, H, dh = 300, 1, 64
