@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 4
+#define SER_ABI_VERSION 5
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -50,6 +50,14 @@ const char* ser_last_error(void);
 /* K1  zero_mean_unit_var_norm (HF feature_extraction_wav2vec2.py:77-97; call site
  * preprocess_speech.py:48).  wav/out: packed fp32 samples; sample_offs[B+1] (device). */
 int ser_wave_norm(const float* wav, const int64_t* sample_offs, int B, float* out, void* stream);
+
+/* K1 + framing for the matrix-core form of conv layer 0: normalise each utterance (as ser_wave_norm)
+ * and write frame t as one act row [x_n[stride*t .. stride*t+k-1], 0, ...] of 64 elements, so that
+ * Conv1d(1,C,k,stride)+LayerNorm+GELU (HF modeling_wavlm.py:696-720) is ser_gemm with K = 64 and the
+ * LayerNorm epilogue.  out: act [total_rows, 64]; work: ser_workspace_bytes(SER_WS_WAVE_FRAMES, B, ...). */
+int ser_wave_frames(const float* wav, const int64_t* sample_offs, const int32_t* frame_offs, int B,
+                    int k, int stride, void* out, int64_t out_plane_stride, int mode, void* work,
+                    int total_rows, void* stream);
 
 /* K2  conv layer 0: Conv1d(1,C,k,stride) [+bias] -> LayerNorm(C) -> GELU
  * (HF modeling_wavlm.py:696-720).  One output row per frame.
@@ -178,6 +186,7 @@ int ser_mean4(const float* s0, const float* s1, const float* s2, const float* s3
 int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, int64_t n, void* stream);
 
 #define SER_WS_LOGMEL 1
+#define SER_WS_WAVE_FRAMES 2
 size_t ser_workspace_bytes(int op, int B, int T, int D, int H, int mode);
 
 #ifdef __cplusplus

@@ -17,7 +17,8 @@ MODE_FP32X = 2
 ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
-ABI_VERSION = 4
+WS_WAVE_FRAMES = 2
+ABI_VERSION = 5
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -46,6 +47,8 @@ _SIGNATURES = {
     "ser_version": (c_int, []),
     "ser_last_error": (C.c_char_p, []),
     "ser_wave_norm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ser_wave_frames": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_int, c_void_p,
+                                c_int, c_void_p]),
     "ser_conv0_ln_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ser_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),

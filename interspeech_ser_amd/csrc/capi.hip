@@ -31,6 +31,8 @@ extern "C" size_t ser_workspace_bytes(int op, int B, int T, int D, int H, int mo
         case SER_WS_LOGMEL:
             // one 256-byte granule per utterance (running max) + the fp64 twiddle table [400][201]x2
             return (size_t)(B > 0 ? B : 1) * 256 + (size_t)400 * 201 * 16;
+        case SER_WS_WAVE_FRAMES:
+            return (size_t)(B > 0 ? B : 1) * 64 * 2 * sizeof(double);      // [B][64] partial (sum, sum^2)
         default:
             return 0;
     }

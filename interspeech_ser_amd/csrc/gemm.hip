@@ -252,54 +252,40 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         // LayerNorm over the full row (N <= BN, one N tile) + GELU, two-pass statistics.
         // Row partials cross the WN waves of a block row through LDS (the ring is idle now).
         __syncthreads();
-        float* red = (float*)lds;                                     // [BM][WN]
+        float* red = (float*)lds;                                     // [BM][WN][2]
         const float invN = 1.0f / (float)p.N;
         float mean[TM], rstd[TM];
+        // one exchange: per-row (sum, sum of squares) partials of the WN waves of a block row.
+        // (fp32 accumulators, |mean| << std for conv outputs: E[x^2]-mean^2 is safe here)
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-            float s = 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float x = acc[ni][mi][r] + bias[ni * 4 + r];
                     acc[ni][mi][r] = x;
-                    if (ncol0 + ni * 4 + r < p.N) s += x;
+                    if (ncol0 + ni * 4 + r < p.N) { s1 += x; s2 += x * x; }
                 }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (fq == 0) red[(wm * TM * 16 + mi * 16 + frow) * WN + wn] = s;
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (fq == 0) {
+                red[((wm * TM * 16 + mi * 16 + frow) * WN + wn) * 2] = s1;
+                red[((wm * TM * 16 + mi * 16 + frow) * WN + wn) * 2 + 1] = s2;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-            float s = 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < WN; ++w) s += red[(wm * TM * 16 + mi * 16 + frow) * WN + w];
-            mean[mi] = s * invN;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            float s = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = acc[ni][mi][r] - mean[mi];
-                    if (ncol0 + ni * 4 + r < p.N) s += d * d;
-                }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (fq == 0) red[(wm * TM * 16 + mi * 16 + frow) * WN + wn] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < WN; ++w) s += red[(wm * TM * 16 + mi * 16 + frow) * WN + w];
-            rstd[mi] = rsqrtf(s * invN + p.ln_eps);
+            for (int w = 0; w < WN; ++w) {
+                s1 += red[((wm * TM * 16 + mi * 16 + frow) * WN + w) * 2];
+                s2 += red[((wm * TM * 16 + mi * 16 + frow) * WN + w) * 2 + 1];
+            }
+            mean[mi] = s1 * invN;
+            rstd[mi] = rsqrtf(fmaxf(s2 * invN - mean[mi] * mean[mi], 0.f) + p.ln_eps);
         }
         float lg[CPL], lb[CPL];
 #pragma unroll
@@ -318,21 +304,22 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             if (m >= p.M) continue;
             const int64_t orow = p.out_rowmap ? (int64_t)p.out_rowmap[m] : (int64_t)m;
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                if (ncol0 + ni * 4 >= p.N) continue;
-                float v[4];
+            for (int ni = 0; ni < TN; ni += 2) {                      // 8 columns = one 16-byte act store
+                if (ncol0 + ni * 4 >= p.N) continue;                  // N % 8 == 0: a pair is valid or not as a whole
+                float v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = (acc[ni][mi][r] - mean[mi]) * rstd[mi] * lg[ni * 4 + r] + lb[ni * 4 + r];
+                for (int r = 0; r < 8; ++r) {
+                    const int nj = ni + (r >> 2), rr = r & 3;
+                    float x = (acc[nj][mi][rr] - mean[mi]) * rstd[mi] * lg[nj * 4 + rr] + lb[nj * 4 + rr];
                     v[r] = (p.act == SER_ACT_GELU) ? gelu_erf(x) : x;
                 }
                 if (p.out_f32) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4) = o;
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4) = o0;
+                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4 + 4) = o1;
                 }
                 if (p.out_act)
-                    store_act4<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4,
-                                     p.out_plane_stride, v[0], v[1], v[2], v[3]);
+                    store_act8<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4, p.out_plane_stride, v);
             }
         }
     } else {
@@ -349,30 +336,34 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
             float st1 = 0.f, st2 = 0.f;
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                if (ncol0 + ni * 4 >= p.N) continue;
-                float v[4];
+            for (int ni = 0; ni < TN; ni += 2) {                      // 8 columns per step: 16-byte act stores
+                if (ncol0 + ni * 4 >= p.N) continue;                  // N % 8 == 0: a pair is valid or not as a whole
+                float v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 8; ++r) {
+                    const int nj = ni + (r >> 2), rr = r & 3;
                     // LN(x) W^T = rstd * (x W'^T - mu * colsum(W')) + (beta W^T + b)
-                    float x = fmaf(rs, acc[ni][mi][r] - mu * csum[ni * 4 + r], bias[ni * 4 + r]);
-                    if (ncol0 + ni * 4 < p.col_scale_end) x *= p.col_scale;        // e.g. q *= dh^-0.5 * log2(e)
+                    float x = fmaf(rs, acc[nj][mi][rr] - mu * csum[nj * 4 + rr], bias[nj * 4 + rr]);
+                    if (ncol0 + nj * 4 < p.col_scale_end) x *= p.col_scale;        // e.g. q *= dh^-0.5 * log2(e)
                     if (p.act == SER_ACT_GELU) x = gelu_erf(x);
                     v[r] = x;
                 }
                 if (p.residual) {
-                    const f32x4 rr = *(const f32x4*)(p.residual + (int64_t)rrow * p.ldr + gcol + ni * 4);
-                    v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+                    const float* rp = p.residual + (int64_t)rrow * p.ldr + gcol + ni * 4;
+                    const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+                    v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
+                    v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
                 }
-                st1 += (v[0] + v[1]) + (v[2] + v[3]);
-                st2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
                 if (p.out_f32 && ncol0 + ni * 4 >= p.f32_col_begin) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4 - p.f32_col_begin) = o;
+                    float* op = p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4 - p.f32_col_begin;
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *(f32x4*)op = o0;
+                    *(f32x4*)(op + 4) = o1;
                 }
                 if (p.out_act)
-                    store_act4<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4,
-                                     p.out_plane_stride, v[0], v[1], v[2], v[3]);
+                    store_act8<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4, p.out_plane_stride, v);
             }
             if (p.stat_out) {
                 // row partials over this wave's 64 columns (deterministic: one slot per 64-column group)
@@ -395,7 +386,7 @@ enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3 };
 template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI>
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int LDS = ST * (BM + BN) * BK * 2 + BM * 8;      // ring + [BM][2] row statistics
+    constexpr int LDS = ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8);   // ring (+ [BM][2] row statistics)
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     if (a->mode == SER_MODE_BF16) {
@@ -455,11 +446,12 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->stat_out && (a->ln_gamma || a->stat_groups < a->groups * ((a->N + 63) / 64)))
         return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
-    if (a->f32_col_begin < 0 || (a->f32_col_begin % 4)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 4");
+    if ((a->ldo_act % 8) || (a->c_group_stride % 8)) return ser_fail(-18, "ser_gemm: act pitch / group stride must be multiples of 8");
+    if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
     if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
     hipStream_t s = (hipStream_t)stream;
     switch (pick_cfg(a)) {
-        case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 32, 3, true>(a, s);
+        case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 32, 2, true>(a, s);     // 80 KiB ring -> 2 blocks/CU
         case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
         case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
         default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);

@@ -49,6 +49,84 @@ extern "C" int ser_wave_norm(const float* wav, const int64_t* sample_offs, int B
     return ser_check_launch("ser_wave_norm");
 }
 
+// ------------------------------------------------------------------------- K1 + im2col
+// Waveform front door for the matrix-core conv0: per-utterance zero-mean/unit-variance (K1) fused
+// with the framing of conv layer 0 -- every frame t becomes one 128-byte act row
+// [x_n[s*t .. s*t+k-1], 0 ...] (K padded to 64), so Conv1d(1,C,k,s)+LayerNorm+GELU runs as the
+// LN-epilogue GEMM and the normalised waveform never exists in HBM as fp32.
+__global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict__ wav, const int64_t* __restrict__ offs,
+                                                         double* __restrict__ part /*[B][64][2]*/) {
+    __shared__ double red[2][4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int64_t s0 = offs[b], n = offs[b + 1] - s0;
+    const int64_t per = (n + 63) / 64;
+    const int64_t lo = chunk * per, hi = (lo + per < n) ? lo + per : n;
+    double a1 = 0.0, a2 = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const double x = (double)wav[s0 + i]; a1 += x; a2 += x * x; }
+    for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((int64_t)b * 64 + chunk) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        part[((int64_t)b * 64 + chunk) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wave_frames_kernel(const float* __restrict__ wav, const int64_t* __restrict__ soffs,
+                                                          const int32_t* __restrict__ foffs, const double* __restrict__ part,
+                                                          unsigned short* __restrict__ out, int64_t plane, int k, int stride) {
+    __shared__ float stat[2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int64_t s0 = soffs[b], n = soffs[b + 1] - s0;
+    if (tid < 64) {
+        double a1 = part[((int64_t)b * 64 + tid) * 2], a2 = part[((int64_t)b * 64 + tid) * 2 + 1];
+        for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        if (tid == 0) {
+            const double mean = a1 / (double)n;
+            const double var = a2 / (double)n - mean * mean;
+            stat[0] = (float)mean;
+            stat[1] = 1.0f / sqrtf((float)(var > 0.0 ? var : 0.0) + 1e-7f);
+        }
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    const int row_begin = foffs[b], T = foffs[b + 1] - row_begin;
+    const float* x = wav + s0;
+    const int c = tid & 7;                                        // 16-byte chunk of the 128-byte row
+    for (int t = blockIdx.x * 32 + (tid >> 3); t < T; t += gridDim.x * 32) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = c * 8 + i;
+            v[i] = (j < k) ? (x[(int64_t)t * stride + j] - mean) * rstd : 0.f;
+        }
+        unsigned short* dst = out + (int64_t)(row_begin + t) * 64 + c * 8;
+        store_act4<MODE>(dst, plane, v[0], v[1], v[2], v[3]);
+        store_act4<MODE>(dst + 4, plane, v[4], v[5], v[6], v[7]);
+    }
+}
+
+extern "C" int ser_wave_frames(const float* wav, const int64_t* sample_offs, const int32_t* frame_offs, int B, int k,
+                               int stride, void* out, int64_t out_plane_stride, int mode, void* work, int total_rows,
+                               void* stream) {
+    if (!wav || !sample_offs || !frame_offs || !out || !work) return ser_fail(-1, "ser_wave_frames: null pointer");
+    if (B <= 0 || k < 1 || k > 64 || stride < 1 || total_rows <= 0) return ser_fail(-2, "ser_wave_frames: bad B/k/stride/rows");
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_wave_frames: bad mode");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wave_stats_kernel, dim3(64, B), dim3(256), 0, s, wav, sample_offs, (double*)work);
+    int blocks = ((total_rows + B - 1) / B + 31) / 32;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_FP32X>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
+                           (const double*)work, (unsigned short*)out, out_plane_stride, k, stride);
+    else
+        hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_BF16>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
+                           (const double*)work, (unsigned short*)out, out_plane_stride, k, stride);
+    return ser_check_launch("ser_wave_frames");
+}
+
 // ------------------------------------------------------------------------------- K2
 // Wave per GROUP of frames: consecutive frames overlap in the waveform (stride < kernel), so ONE
 // coalesced 64-sample load serves `rpg` frames (8 for k=10, stride=5); taps are broadcast with

@@ -84,6 +84,28 @@ __device__ __forceinline__ void store_act4(unsigned short* dst, int64_t plane, f
     }
 }
 
+// 8 consecutive values -> one 16-byte store per plane (dst 16-byte aligned): half the store
+// instructions of two store_act4 -- epilogue store tails are issue-bound, not bandwidth-bound.
+template <int MODE>
+__device__ __forceinline__ void store_act8(unsigned short* dst, int64_t plane, const float (&v)[8]) {
+    if (MODE == SER_MODE_BF16) {
+        u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)dst = o;
+    } else {
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split_bf(v[i], h[i], l[i]);
+        u32x4 oh, ol;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            oh[i] = (unsigned)h[2 * i] | ((unsigned)h[2 * i + 1] << 16);
+            ol[i] = (unsigned)l[2 * i] | ((unsigned)l[2 * i + 1] << 16);
+        }
+        *(u32x4*)dst = oh;
+        *(u32x4*)(dst + plane) = ol;
+    }
+}
+
 // Load 8 consecutive act elements as fp32 (hi [+ lo]).
 template <int MODE>
 __device__ __forceinline__ void load_act8(const unsigned short* src, int64_t plane, float (&v)[8]) {

@@ -373,6 +373,12 @@ class SpeechEncoder(_EncoderBase):
         p0 = "feature_extractor.conv_layers.0"
         self.conv0_w = self._dev_f32(sd[p0 + ".conv.weight"].reshape(C0, geo.conv_kernel[0]))
         self.conv0_b = self._dev_f32(sd[p0 + ".conv.bias"]) if geo.conv_bias else None
+        # matrix-core form of conv layer 0: taps zero-padded to K = 64 (frames come from ser_wave_frames)
+        if geo.conv_kernel[0] > 64:
+            raise NotImplementedError("conv layer 0 kernel wider than 64 taps")
+        w0 = torch.zeros((C0, 64), dtype=torch.float32)
+        w0[:, : geo.conv_kernel[0]] = sd[p0 + ".conv.weight"].reshape(C0, geo.conv_kernel[0]).float()
+        self.conv0 = self._linear(w0, sd[p0 + ".conv.bias"] if geo.conv_bias else None)
         self.conv_ln = [self._ln_pair(sd, f"feature_extractor.conv_layers.{i}.layer_norm") for i in range(len(geo.conv_dim))]
         self.convs: List[Linear] = []
         for i in range(1, len(geo.conv_dim)):
@@ -448,7 +454,9 @@ class SpeechEncoder(_EncoderBase):
                                         dtype=torch.int32, device=dev)
         # buffers
         Fd = geo.ffn
-        pl["wave_norm"] = torch.empty(int(sum(key)), dtype=torch.float32, device=dev)
+        pl["frames"] = self._new_act(pl["rows"][0], 64)
+        pl["wave_work"] = torch.empty(lib.ser_workspace_bytes(_lib.WS_WAVE_FRAMES, B, 0, 0, 0, self.mode),
+                                      dtype=torch.uint8, device=dev)
         pl["conv_act"] = [self._new_act(pl["rows"][0], C0), self._new_act(pl["rows"][1], C0)]   # ping-pong
         pl["feat_f32"] = torch.empty((M, C0), dtype=torch.float32, device=dev)
         pl["feat_act"] = self._new_act(M, C0)
@@ -484,16 +492,15 @@ class SpeechEncoder(_EncoderBase):
         pl = self._plan(lengths, slot)
         B, M, D, C0 = pl["B"], pl["M"], geo.hidden, geo.conv_dim[0]
         st = _stream()
-        # a6: zero-mean / unit-variance per utterance
-        check(lib.ser_wave_norm(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), B, pl["wave_norm"].data_ptr(), st),
-              "ser_wave_norm")
-        # a7: conv layer 0 (direct) + LN + GELU
+        # a6 + a7 (layer 0): zero-mean / unit-variance per utterance fused with framing, then
+        # Conv1d(1,C,10,5)+LayerNorm+GELU on the matrix cores (K padded to 64, LayerNorm epilogue)
+        fr = pl["frames"]
+        check(lib.ser_wave_frames(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr(), B,
+                                  geo.conv_kernel[0], geo.conv_stride[0], fr.ptr, fr.plane_stride, self.mode,
+                                  pl["wave_work"].data_ptr(), pl["rows"][0], st), "ser_wave_frames")
         a_in = pl["conv_act"][0]
-        check(lib.ser_conv0_ln_gelu(pl["wave_norm"].data_ptr(), pl["sample_offs"].data_ptr(),
-                                    pl["frame_offs0"].data_ptr(), B, self.conv0_w.data_ptr(), _ptr(self.conv0_b),
-                                    self.conv_ln[0][0].data_ptr(), self.conv_ln[0][1].data_ptr(),
-                                    a_in.ptr, a_in.plane_stride, self.mode, C0, geo.conv_kernel[0], geo.conv_stride[0],
-                                    pl["rows"][0], st), "ser_conv0_ln_gelu")
+        self._gemm(fr, self.conv0, pl["rows"][0], act=_lib.ACT_GELU, ln=self.conv_ln[0], ln_eps=1e-5, out_act=a_in,
+                   k_algo=geo.conv_kernel[0])
         # a7: conv layers 1..6 as implicit GEMMs with LayerNorm(C)+GELU fused into the epilogue
         # (the 512-wide output row lives in one block tile, so the pre-LN activations never touch HBM)
         nl = len(geo.conv_dim)

@@ -345,6 +345,45 @@ def test_conv0_ln_gelu(L, mode, Cc, bias):
     assert err < (4e-2 if mode == 1 else 2e-4), err
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_wave_frames_feeds_matrix_core_conv0(L, mode):
+    """ser_wave_frames (normalise + framing) -> ser_gemm(K=64, LayerNorm+GELU epilogue) == Conv1d(1,C,10,5) -> LN -> GELU
+    of the HF-normalised waveform, for a ragged pair."""
+    lens, k, s, Cc = [3000, 1207], 10, 5, 512
+    rng = np.random.default_rng(1)
+    waves = [(0.1 * rng.standard_normal(n) + 0.02).astype(np.float32) for n in lens]
+    T = [(n - k) // s + 1 for n in lens]
+    rows = sum(T)
+    packed = torch.from_numpy(np.concatenate(waves)).to(DEV)
+    soffs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=DEV)
+    foffs = torch.tensor(np.concatenate([[0], np.cumsum(T)]), dtype=torch.int32, device=DEV)
+    planes = 2 if mode == 2 else 1
+    frames = torch.empty(planes, rows, 64, dtype=torch.bfloat16, device=DEV)
+    work = torch.empty(L.lib.ser_workspace_bytes(L.WS_WAVE_FRAMES, 2, 0, 0, 0, mode), dtype=torch.uint8, device=DEV)
+    L.check(L.lib.ser_wave_frames(packed.data_ptr(), soffs.data_ptr(), foffs.data_ptr(), 2, k, s, frames.data_ptr(),
+                                  rows * 64, mode, work.data_ptr(), rows, stream()))
+    torch.cuda.synchronize()
+    fv = act_value(frames).cpu()
+    o = 0
+    for b, w in enumerate(waves):
+        xn = (w - w.mean()) / np.sqrt(w.var() + 1e-7)                      # HF zero_mean_unit_var_norm
+        ref = np.stack([xn[s * t: s * t + k] for t in range(T[b])])
+        assert np.abs(fv[o:o + T[b], :k].numpy() - ref).max() < (2e-2 if mode == 1 else 3e-5)
+        assert torch.count_nonzero(fv[o:o + T[b], k:]) == 0
+        o += T[b]
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(Cc, 1, k, generator=g) * 0.5
+    lw, lb = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    wp = torch.zeros(Cc, 64)
+    wp[:, :k] = w[:, 0]
+    Wa = to_act(wp, mode)
+    pre = fv.double() @ act_value(Wa).cpu().double().T
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(pre, (Cc,), lw.double(), lb.double(), 1e-5))
+    _, oact = run_gemm(L, frames, Wa, rows, Cc, 64, mode, act=1, ln=(lw.to(DEV), lb.to(DEV)), want_act=True, want_f32=False)
+    err = (act_value(oact).cpu().double() - ref).abs().max().item()
+    assert err < (4e-2 if mode == 1 else 3e-4), err
+
+
 def test_bias_table_bit_exact(L, golden_dir):
     """Bucket function against the committed HF table for rel in [-1500, 1500] (integer gate)."""
     gold = np.load(os.path.join(golden_dir, "integer_tables.npz"))
