@@ -451,7 +451,7 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
     hipStream_t s = (hipStream_t)stream;
     switch (pick_cfg(a)) {
-        case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 32, 2, true>(a, s);     // 80 KiB ring -> 2 blocks/CU
+        case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 64, 2, true>(a, s);     // 160 KiB ring, one barrier per 64-deep K tile
         case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
         case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
         default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
