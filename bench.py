@@ -132,16 +132,21 @@ def main():
     packed = enc.upload(waves)
     torch.cuda.synchronize()
 
+    # The batch is processed as `micro` utterance groups (parallel branches of one hipGraph): every
+    # launch of the step, timed or traced, has the group's shape.
+    micro = args.micro if (args.micro > 1 and args.batch % args.micro == 0) else 1
+    per = args.batch // micro
+    groups = [(enc.upload(waves[i * per:(i + 1) * per]), lengths[i * per:(i + 1) * per]) for i in range(micro)]
+    torch.cuda.synchronize()
+
+    def eager_step():
+        for slot, (w, l) in enumerate(groups):
+            enc.forward(w, l, slot=slot)
+
     if args.no_graph:
-        step = lambda: enc.forward(packed, lengths)
-    elif args.micro > 1 and args.batch % args.micro == 0:
-        per = args.batch // args.micro
-        groups = [(enc.upload(waves[i * per:(i + 1) * per]), lengths[i * per:(i + 1) * per]) for i in range(args.micro)]
-        torch.cuda.synchronize()
-        graph, hs = enc.capture_concurrent(groups)
-        step = graph.replay
+        step = eager_step
     else:
-        graph, hs = enc.capture(packed, lengths)
+        graph, hs = enc.capture_concurrent(groups)
         step = graph.replay
     for _ in range(args.warmup):
         step()
@@ -163,7 +168,7 @@ def main():
     if not args.no_trace:
         enc.gemm_trace = []
         for _ in range(args.steps):
-            enc.forward(packed, lengths)
+            eager_step()
         torch.cuda.synchronize()
         trace, enc.gemm_trace = enc.gemm_trace, None
 
@@ -185,7 +190,7 @@ def main():
                        "frames_per_utt": geo.max_source_positions if whisper else geo.frames_for(num_samples), "gflop_per_utt": round(gf_utt, 1),
                        "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
             "achieved_tflops_whole_path": round(value * gf_utt / 1e3 / world, 1),
-            "launch": "eager" if args.no_graph else f"hipGraph replay, {args.micro} concurrent utterance group(s)",
+            "launch": "eager" if args.no_graph else f"hipGraph replay, {micro} concurrent utterance group(s) of {per}",
             "weight_broadcast_s": round(bcast_s, 4),
         }
         if trace:
