@@ -310,8 +310,14 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int nj = ni + (r >> 2), rr = r & 3;
-                    float x = (acc[nj][mi][rr] - mean[mi]) * rstd[mi] * lg[nj * 4 + rr] + lb[nj * 4 + rr];
-                    v[r] = (p.act == SER_ACT_GELU) ? gelu_erf(x) : x;
+                    v[r] = (acc[nj][mi][rr] - mean[mi]) * rstd[mi] * lg[nj * 4 + rr] + lb[nj * 4 + rr];
+                }
+                if (p.act == SER_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const f32x2 y = gelu_erf2((f32x2){v[r], v[r + 1]});
+                        v[r] = y[0]; v[r + 1] = y[1];
+                    }
                 }
                 if (p.out_f32) {
                     f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
@@ -345,8 +351,14 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     // LN(x) W^T = rstd * (x W'^T - mu * colsum(W')) + (beta W^T + b)
                     float x = fmaf(rs, acc[nj][mi][rr] - mu * csum[nj * 4 + rr], bias[nj * 4 + rr]);
                     if (ncol0 + nj * 4 < p.col_scale_end) x *= p.col_scale;        // e.g. q *= dh^-0.5 * log2(e)
-                    if (p.act == SER_ACT_GELU) x = gelu_erf(x);
                     v[r] = x;
+                }
+                if (p.act == SER_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const f32x2 y = gelu_erf2((f32x2){v[r], v[r + 1]});
+                        v[r] = y[0]; v[r + 1] = y[1];
+                    }
                 }
                 if (p.residual) {
                     const float* rp = p.residual + (int64_t)rrow * p.ldr + gcol + ni * 4;

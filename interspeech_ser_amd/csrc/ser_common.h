@@ -56,6 +56,35 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
 
+// Two GELUs at once on packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32): the Horner chains of the
+// rational erf are the bulk of the FC1 / conv epilogues, and packed FMAs halve their issue slots.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    const f32x2 a = v * 0.70710678118654752440f;
+    f32x2 x;
+    x[0] = fminf(fmaxf(a[0], -4.0f), 4.0f);
+    x[1] = fminf(fmaxf(a[1], -4.0f), 4.0f);
+    const f32x2 x2 = x * x;
+    f32x2 p = {-2.72614225801306e-10f, -2.72614225801306e-10f};
+    p = __builtin_elementwise_fma(p, x2, (f32x2){2.77068142495902e-08f, 2.77068142495902e-08f});
+    p = __builtin_elementwise_fma(p, x2, (f32x2){-2.10102402082508e-06f, -2.10102402082508e-06f});
+    p = __builtin_elementwise_fma(p, x2, (f32x2){-5.69250639462346e-05f, -5.69250639462346e-05f});
+    p = __builtin_elementwise_fma(p, x2, (f32x2){-7.34990630326855e-04f, -7.34990630326855e-04f});
+    p = __builtin_elementwise_fma(p, x2, (f32x2){-2.95459980854025e-03f, -2.95459980854025e-03f});
+    p = __builtin_elementwise_fma(p, x2, (f32x2){-1.60960333262415e-02f, -1.60960333262415e-02f});
+    f32x2 q = {-1.45660718464996e-05f, -1.45660718464996e-05f};
+    q = __builtin_elementwise_fma(q, x2, (f32x2){-2.13374055278905e-04f, -2.13374055278905e-04f});
+    q = __builtin_elementwise_fma(q, x2, (f32x2){-1.68282697438203e-03f, -1.68282697438203e-03f});
+    q = __builtin_elementwise_fma(q, x2, (f32x2){-7.37332916720468e-03f, -7.37332916720468e-03f});
+    q = __builtin_elementwise_fma(q, x2, (f32x2){-1.42647390514189e-02f, -1.42647390514189e-02f});
+    f32x2 r;
+    r[0] = __frcp_rn(q[0]);
+    r[1] = __frcp_rn(q[1]);
+    const f32x2 e = x * p * r;                                  // erf
+    const f32x2 h = v * 0.5f;
+    return __builtin_elementwise_fma(h, e, h);                  // 0.5 v (1 + erf)
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
