@@ -379,7 +379,13 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     const int np = mode == SER_MODE_FP32X ? 2 : 1;
     const int nch = ABKV * (dhp / 8) / 256;
     const int nbuf = (nch * 2 * np <= 8) ? 2 : 1;
-    const int bias_stride = table ? ((2 * max_frames + ABKV + 3) / 4) * 4 : 0;
+    // copy stride == 16 (mod 64) floats: the 4 shifted copies x the 4 query phases of a ds_read_b128
+    // lane group then land on 16 distinct 4-bank slots (a multiple of 64 made them 2-way conflicts)
+    int bias_stride = 0;
+    if (table) {
+        bias_stride = ((2 * max_frames + ABKV + 3) / 4) * 4;
+        bias_stride += (16 - (bias_stride & 63) + 64) & 63;
+    }
     const size_t lds = (size_t)nbuf * 2 * np * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
     if (lds > 160 * 1024) return ser_fail(-8, "ser_attention: LDS need %zu > 160 KiB (max_frames=%d)", lds, max_frames);
     AttnParams p;
