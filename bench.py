@@ -88,6 +88,44 @@ def cpu_baseline(geo, sd, num_samples, n_clips=6):
             "sample": f"{n_clips} x {num_samples / 16000:.0f} s clips, batch of 1, 4-thread driver, fp32 PyTorch-CPU oracle"}
 
 
+def bench_text(args, geo, rank, world, device, D):
+    """Next row 8f-1: RoBERTa text extraction, `--batch` texts of `--max_len` tokens per step (synthetic ids)."""
+    from interspeech_ser_amd.engine import TextEncoder
+    sd, bcast_s = broadcast_weights(geo, 0, rank)
+    enc = TextEncoder(geo, sd, device, args.mode)
+    T = args.max_len
+    g = torch.Generator().manual_seed(99 + rank)
+    lens = torch.randint(8, T + 1, (args.batch,), generator=g)
+    ids = torch.randint(3, geo.vocab_size, (args.batch, T), generator=g)
+    ids[torch.arange(T)[None, :] >= lens[:, None]] = geo.pad_token_id
+    ids_d, kl_d = ids.to(device=device, dtype=torch.int32), lens.to(device=device, dtype=torch.int32)
+    enc.forward_device(ids_d, kl_d)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        enc.forward_device(ids_d, kl_d)
+    for _ in range(args.warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        Dm, F, L = geo.hidden, geo.ffn, geo.num_layers
+        gf = L * (2.0 * T * Dm * 3 * Dm + 2.0 * T * Dm * Dm + 4.0 * T * T * Dm + 4.0 * T * Dm * F) / 1e9
+        value = args.batch * args.steps * world / elapsed
+        print(json.dumps({"metric": f"texts/sec ({T} tokens) {geo.name} embed extract", "value": round(value, 1),
+                          "unit": "texts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16" if args.mode == "bf16" else "bf16x3 (fp32-grade split)",
+                          "data": "synthetic", "config": {"workload": f"{geo.name} text embed extract, batch={args.batch} x {T} tokens, mode={args.mode}",
+                                                          "gflop_per_text": round(gf, 1)},
+                          "achieved_tflops_whole_path": round(value * gf / 1e3 / world, 1)}), flush=True)
+    D.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--max_len", type=int, default=80, help="tokens per text (roberta workloads)")
     ap.add_argument("--ssl_type", type=str, default="microsoft/wavlm-large")
     ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x"])
     ap.add_argument("--layers", type=int, default=0, help="debug: truncate the encoder (invalidates the metric)")
@@ -123,6 +162,8 @@ def main():
     if args.layers:
         geo = C.with_layers(geo, args.layers)
     whisper = geo.family == C.FAMILY_WHISPER
+    if geo.family == C.FAMILY_ROBERTA:
+        return bench_text(args, geo, rank, world, device, D)
     num_samples = int(round(args.seconds * 16000))
 
     sd, bcast_s = broadcast_weights(geo, 0, rank)

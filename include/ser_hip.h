@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 5
+#define SER_ABI_VERSION 6
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -163,7 +163,15 @@ int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, 
                   const float* table, int table_T, const float* gate,
                   void* out, int64_t ldo, int64_t out_plane_stride,
                   int H, int dh, float scale, int mode,
-                  int gate_col, const float* gru_const /*[H]*/, void* stream);
+                  int gate_col, const float* gru_const /*[H]*/,
+                  const int32_t* key_lens /*[B] or NULL: keys >= key_lens[b] are padding (RoBERTa attention_mask)*/,
+                  void* stream);
+
+/* next row 8f-1 (text side): RoBERTa embeddings word[id] + position[cumsum(non-pad)] + token_type[0] -> LayerNorm
+ * (HF modeling_roberta.py:56-155; call site preprocessing/preprocess_roberta.py:47-57).  ids: [B,T] int32. */
+int ser_embed_ln(const int32_t* ids, const float* word_emb, const float* pos_emb, const float* type_emb,
+                 const float* ln_g, const float* ln_b, float eps, float* out_f32, void* out_act,
+                 int64_t out_plane_stride, int mode, int B, int T, int D, int pad_id, void* stream);
 
 /* K13 Whisper log-mel front end (HF feature_extraction_whisper.py:135-169): packed fp32
  * samples -> [B, n_mels, 3000] fp32 (zero-pad/truncate to 480000, reflect pad, Hann,

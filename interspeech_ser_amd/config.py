@@ -18,6 +18,7 @@ FAMILY_WAVLM = "wavlm"
 FAMILY_WAV2VEC2 = "wav2vec2"
 FAMILY_HUBERT = "hubert"
 FAMILY_WHISPER = "whisper"
+FAMILY_ROBERTA = "roberta"      # text side of the bimodal heads (next row 8f-1)
 
 SPEECH_FAMILIES = (FAMILY_WAVLM, FAMILY_WAV2VEC2, FAMILY_HUBERT)
 
@@ -44,6 +45,11 @@ class EncoderGeometry:
     # Whisper encoder
     n_mels: int = 128
     max_source_positions: int = 1500
+    # RoBERTa text encoder
+    vocab_size: int = 50265
+    max_positions: int = 514
+    pad_token_id: int = 1
+    type_vocab_size: int = 1
     name: str = ""
 
     @property
@@ -88,7 +94,12 @@ WHISPER_LARGE_V3 = EncoderGeometry(
     family=FAMILY_WHISPER, num_layers=32, hidden=1280, heads=20, ffn=5120,
     n_mels=128, max_source_positions=1500, name="openai/whisper-large-v3")
 
+ROBERTA_LARGE = EncoderGeometry(
+    family=FAMILY_ROBERTA, num_layers=24, hidden=1024, heads=16, ffn=4096, name="roberta-large")
+
 _REGISTRY = {
+    "roberta-large": ROBERTA_LARGE,
+    "FacebookAI/roberta-large": ROBERTA_LARGE,
     "microsoft/wavlm-large": WAVLM_LARGE,
     "wavlm-large": WAVLM_LARGE,                       # the reference's argparse default
     "facebook/wav2vec2-xls-r-2b": XLSR_2B,
@@ -104,6 +115,9 @@ def tiny_geometry(family: str, *, hidden: int = 128, heads: int = 2, layers: int
     fixtures under tests/golden (SURVEY 8c item 1).  ``hidden // heads`` selects
     the head-dim code path (64 WavLM/Whisper, 80 HuBERT-XL, 120 XLS-R-2B) and
     ``hidden // pos_groups`` the pos-conv group width (64 / 80 / 120 in the real models)."""
+    if family == FAMILY_ROBERTA:
+        return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads, ffn=ffn,
+                               vocab_size=300, max_positions=90, name=f"tiny-{family}-d{hidden}h{heads}")
     if family == FAMILY_WHISPER:
         return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads,
                                ffn=ffn, n_mels=128, max_source_positions=1500,
@@ -139,3 +153,4 @@ TINY_WAVLM = tiny_geometry(FAMILY_WAVLM, hidden=128, heads=2, ffn=256, pos_group
 TINY_WAV2VEC2 = tiny_geometry(FAMILY_WAV2VEC2, hidden=960, heads=8, ffn=512, pos_groups=8)
 TINY_HUBERT = tiny_geometry(FAMILY_HUBERT, hidden=320, heads=4, ffn=384, pos_groups=4)
 TINY_WHISPER = tiny_geometry(FAMILY_WHISPER, hidden=128, heads=2, ffn=256)
+TINY_ROBERTA = tiny_geometry(FAMILY_ROBERTA, hidden=128, heads=2, ffn=256)

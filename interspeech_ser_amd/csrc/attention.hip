@@ -35,6 +35,7 @@ struct AttnParams {
     int64_t ld, plane;
     int q_col, k_col, v_col;
     const int32_t* frame_offs;
+    const int32_t* key_lens;   // optional [B]: keys >= key_lens[b] are padding (text encoders); queries keep all rows
     const float* table;
     int table_T;
     const float* gate;
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
     if (q0 >= T) return;
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
-    const int nkt = (T + ABKV - 1) / ABKV;
+    const int TK = p.key_lens ? p.key_lens[b] : T;               // attendable keys (== T for speech)
+    const int nkt = (TK + ABKV - 1) / ABKV;
 
     // ---- staging helpers: thread owns chunks c = tid + i*256 of the [64 keys][CPR] tile --------
     u32x4 stg[NP][2][NCH];
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
             const int key = c / CPR, ch = c - key * CPR;
             const int kg = kt * ABKV + key;
             // branch-free: always load from a valid address, zero by select (keys >= T, pad columns >= dh)
-            const bool ok = (kg < T) && (ch * 8 < dh);
+            const bool ok = (kg < TK) && (ch * 8 < dh);
             const unsigned short* src = p.qkv + (int64_t)(row0 + (kg < T ? kg : T - 1)) * p.ld + h * dh
                                       + (ch * 8 < dh ? ch * 8 : 0);
             const unsigned int keep = ok ? 0xffffffffu : 0u;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
         }
     };
 
-    const int nfull = (T & (ABKV - 1)) ? nkt - 1 : nkt;          // tiles without key padding
+    const int nfull = (TK & (ABKV - 1)) ? nkt - 1 : nkt;         // tiles without key padding
     stage_load(0, padded || nfull == 0);
 
     // ---- this head's bias row, 4 shifted copies: copy c [j] = table[h][(table_T-T) + j + c] -------
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = PRE ? st[sub][4 * g4 + r] : fmaf(st[sub][4 * g4 + r], c1, gq2 * bv[r]);
-                    if (RAGGED) v = (kb + r < T) ? v : -INFINITY;
+                    if (RAGGED) v = (kb + r < TK) ? v : -INFINITY;
                     st[sub][4 * g4 + r] = v;
                     mloc = fmaxf(mloc, v);
                 }
@@ -364,7 +366,8 @@ static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStrea
 extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
                              const int32_t* frame_offs, int B, int max_frames, const float* table, int table_T,
                              const float* gate, void* out, int64_t ldo, int64_t out_plane_stride, int H, int dh,
-                             float scale, int mode, int gate_col, const float* gru_const, void* stream) {
+                             float scale, int mode, int gate_col, const float* gru_const, const int32_t* key_lens,
+                             void* stream) {
     if (!qkv || !frame_offs || !out) return ser_fail(-1, "ser_attention: null pointer");
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
@@ -391,7 +394,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     AttnParams p;
     p.qkv = (const unsigned short*)qkv; p.ld = ld; p.plane = plane_stride;
     p.q_col = q_col; p.k_col = k_col; p.v_col = v_col;
-    p.frame_offs = frame_offs; p.table = table; p.table_T = table_T; p.gate = gate;
+    p.frame_offs = frame_offs; p.key_lens = key_lens; p.table = table; p.table_T = table_T; p.gate = gate;
     p.gru_const = gru_const; p.gate_col = gate_col;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;

@@ -318,6 +318,81 @@ extern "C" int ser_layernorm(const float* x, int64_t ldx, const float* g, const 
     return ser_check_launch("ser_layernorm");
 }
 
+// ------------------------------------------------------------------ text embeddings (8f-1)
+// RoBERTa embeddings: word[id] + position[pos] + token_type[0] -> LayerNorm (HF modeling_roberta.py:56-120).
+// Wave per token; position ids = cumsum(non-pad)*non-pad + pad_id, computed per sequence with a wave scan.
+template <int MODE>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, const float* __restrict__ wemb,
+                                                       const float* __restrict__ pemb, const float* __restrict__ temb,
+                                                       const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                       float* __restrict__ of, unsigned short* __restrict__ oa, int64_t plane,
+                                                       int T, int D, int pad_id, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int seq = row / T, t = row - seq * T;
+    // position id: number of non-pad tokens in ids[seq][0..t] (T <= 512), wave-parallel count
+    int cnt = 0;
+    for (int i = lane; i <= t; i += 64) cnt += (ids[seq * T + i] != pad_id);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    const int id = ids[row];
+    const int pos = (id != pad_id) ? cnt + pad_id : pad_id;
+    const float* w = wemb + (int64_t)id * D;
+    const float* pe = pemb + (int64_t)pos * D;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            const f32x4 a = *(const f32x4*)(w + c), p4 = *(const f32x4*)(pe + c), t4 = *(const f32x4*)(temb + c);
+            v[i] = (a + p4) + t4;
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+            if (of) *(f32x4*)(of + (int64_t)row * D + c) = y;
+            if (oa) store_act4<MODE>(oa + (int64_t)row * D + c, plane, y[0], y[1], y[2], y[3]);
+        }
+    }
+}
+
+extern "C" int ser_embed_ln(const int32_t* ids, const float* word_emb, const float* pos_emb, const float* type_emb,
+                            const float* ln_g, const float* ln_b, float eps, float* out_f32, void* out_act,
+                            int64_t out_plane_stride, int mode, int B, int T, int D, int pad_id, void* stream) {
+    if (!ids || !word_emb || !pos_emb || !type_emb || !ln_g || !ln_b || (!out_f32 && !out_act))
+        return ser_fail(-1, "ser_embed_ln: null pointer");
+    if (B <= 0 || T <= 0 || D % 4 || D > 2048) return ser_fail(-2, "ser_embed_ln: bad B/T/D");
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_embed_ln: bad mode");
+    const int rows = B * T;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(embed_ln_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, ids, word_emb, pos_emb, type_emb,
+                           ln_g, ln_b, eps, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, pad_id, rows);
+    else
+        hipLaunchKernelGGL(embed_ln_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, ids, word_emb, pos_emb, type_emb,
+                           ln_g, ln_b, eps, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, pad_id, rows);
+    return ser_check_launch("ser_embed_ln");
+}
+
 // ------------------------------------------------------------------------------ K8a
 __global__ void bias_table_kernel(const float* __restrict__ emb, float* __restrict__ table, int T, int H,
                                   int num_buckets, int max_distance) {

@@ -258,6 +258,118 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
     return 0
 
 
+# ------------------------------------------------------------------ text extractor (8f-1)
+def build_text_parser() -> argparse.ArgumentParser:
+    """Flags of the reference's preprocessing/preprocess_roberta.py:12-21, unchanged, + additive ones."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--seed", type=int, default=7)
+    p.add_argument("--roberta_type", type=str, default="roberta")
+    p.add_argument("--df_path", type=str, default="./")
+    p.add_argument("--save_path", type=str, default="./")
+    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--max_len", type=int, default=80)
+    p.add_argument("--use_average", type=str, default="n")
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "bf16"])
+    p.add_argument("--checkpoint", type=str, default="")
+    p.add_argument("--synthetic_weights", action="store_true")
+    p.add_argument("--tokenizer_path", type=str, default="", help="local RobertaTokenizer files (default: --roberta_type)")
+    return p
+
+
+class TextExtractor:
+    """``tokenizer(text, padding="max_length", truncation=True, max_length=L)`` -> RoBERTa -> [L, D] per text
+    (preprocess_roberta.py:45-76).  ``tokenize`` maps a list of strings to (input_ids, attention_mask) int tensors
+    [n, max_len]; the default uses HF's RobertaTokenizer when its files are available locally."""
+
+    def __init__(self, geo, state_dict, device: str, mode: str, tokenize, average: bool):
+        from .engine import TextEncoder
+        self.enc = TextEncoder(geo, state_dict, device, mode)
+        self.tokenize, self.average = tokenize, average
+
+    def extract(self, texts: Sequence[str]) -> List[torch.Tensor]:
+        from .engine import mean_last4
+        ids, mask = self.tokenize(list(texts))
+        hs = self.enc.forward(ids, mask)
+        sel = mean_last4(hs) if self.average else hs.states[-1]      # .last_hidden_state
+        host = sel.to("cpu")
+        return [host[hs.frame_offs[b]: hs.frame_offs[b + 1]] for b in range(len(texts))]
+
+
+def hf_tokenize_fn(name_or_path: str, max_len: int):
+    """The reference's tokenizer call (preprocess_roberta.py:48-54); raises OSError without local files."""
+    from transformers import RobertaTokenizer
+    tok = RobertaTokenizer.from_pretrained(name_or_path, local_files_only=True)
+
+    def fn(texts):
+        enc = tok(texts, padding="max_length", truncation=True, max_length=max_len, return_tensors="pt")
+        return enc["input_ids"], enc["attention_mask"]
+    return fn
+
+
+def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None) -> int:
+    import pandas as pd
+    from . import dist as D
+    args = build_text_parser().parse_args(argv)
+    rank, world, local_rank = D.env()
+    average = args.use_average == "y"
+    log = print if rank == 0 else (lambda *a, **k: None)
+    log(f"Using average = {average}")
+    log(f"Using device = {'cuda' if torch.cuda.is_available() else 'cpu'}")
+    os.makedirs(args.save_path, exist_ok=True)
+    log(f"Save path = {args.save_path} created. It has {len(os.listdir(args.save_path))} files in it.")
+    log(f"Reading dataframe {args.df_path}")
+    try:
+        df = pd.read_csv(args.df_path)
+        texts, names = [str(t) for t in df.transcription.values], [str(n) for n in df.FileName.values]
+    except Exception as e:                                # noqa: BLE001 (reference: except Exception -> print)
+        log(f"Error reading dataframe from {args.df_path}: {e}")
+        log("Something went wrong, make sure everything is correct before running again!")
+        return 0
+    log(f"Extracting features using {args.roberta_type}")
+    if not torch.cuda.is_available():
+        print("Error: no MI355X visible -- this build has no CPU path (the CPU oracle under oracle/ is test-only)")
+        return 0
+    torch.cuda.set_device(local_rank)
+    D.init(device=torch.device("cuda", local_rank))
+    try:
+        geo = C.geometry_for(args.roberta_type)
+        if geo.family != C.FAMILY_ROBERTA:
+            raise OSError(f"{args.roberta_type} is not a RoBERTa encoder")
+        if tokenize is None:
+            tokenize = hf_tokenize_fn(args.tokenizer_path or args.roberta_type, args.max_len)
+        sd = None
+        if rank == 0:
+            sd, src = find_weights(args.roberta_type, args.checkpoint, args.synthetic_weights, args.seed, geo)
+        sd, _, _ = D.broadcast_state_dict(sd)
+        ex = TextExtractor(geo, sd, f"cuda:{local_rank}", args.mode, tokenize, average)
+    except OSError as e:
+        log(f"Error: No pretrained model found with the name {args.roberta_type}")
+        log(f"  ({e})")
+        D.shutdown()
+        return 0
+    mine = list(range(rank, len(texts), world))
+    from tqdm import tqdm
+    bar = tqdm(total=len(mine), desc="Extracting features", disable=(rank != 0))
+    with ThreadPoolExecutor(max_workers=max(1, args.num_workers)) as pool:
+        writes = []
+        for i in range(0, len(mine), max(1, args.batch_size)):
+            idx = mine[i:i + args.batch_size]
+            try:
+                feats = ex.extract([texts[j] for j in idx])
+                for j, f in zip(idx, feats):
+                    writes.append(pool.submit(save_feature, f, feature_path(args.save_path, names[j])))
+            except Exception as e:                        # noqa: BLE001
+                for j in idx:
+                    print(f"Failed to process {names[j]}: {e}")
+            bar.update(len(idx))
+        for w in writes:
+            w.result()
+    bar.close()
+    D.shutdown()
+    return 0
+
+
 def run_speech(argv: Optional[Sequence[str]] = None) -> int:
     return _run(argv, whisper=False)
 

@@ -27,7 +27,7 @@ import torch
 
 from . import _lib
 from ._lib import GemmArgs, check, lib
-from .config import EncoderGeometry, FAMILY_WAVLM, FAMILY_WHISPER
+from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
 MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X}
 
@@ -203,11 +203,11 @@ class _EncoderBase:
                                 self.mode, rows, D, _stream()), "ser_layernorm")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
-                   gru_const=None):
+                   gru_const=None, key_lens=None):
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
         check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
                                 max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
-                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _stream()),   # q is pre-scaled
+                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _ptr(key_lens), _stream()),   # q is pre-scaled
               "ser_attention")
 
     @staticmethod
@@ -633,6 +633,95 @@ class WhisperEncoder(_EncoderBase):
         return HiddenStates(states, pl["frame_offs_host"])
 
 
+class TextEncoder(_EncoderBase):
+    """RoBERTa text encoder (next row 8f-1: preprocessing/preprocess_roberta.py) on the same kernels:
+    embeddings + L post-LayerNorm BERT layers.  ``forward(input_ids [B,T], attention_mask [B,T])`` returns
+    L+1 states per sequence, ALL T rows each (the reference saves the padded positions too); padded KEYS
+    are excluded through per-sequence key lengths (tokenizer padding="max_length" pads on the right)."""
+
+    def __init__(self, geo: EncoderGeometry, state_dict, device="cuda:0", mode: str = "bf16"):
+        super().__init__(geo, device, mode)
+        if geo.family != FAMILY_ROBERTA:
+            raise ValueError("TextEncoder needs a roberta geometry")
+        sd = state_dict
+        D = geo.hidden
+        self.wemb = self._dev_f32(sd["embeddings.word_embeddings.weight"])
+        self.pemb = self._dev_f32(sd["embeddings.position_embeddings.weight"])
+        self.temb = self._dev_f32(sd["embeddings.token_type_embeddings.weight"][0])
+        self.emb_ln = self._ln_pair(sd, "embeddings.LayerNorm")
+        self.layers = []
+        for i in range(geo.num_layers):
+            p = f"encoder.layer.{i}"
+            a = p + ".attention.self"
+            qkv_w = torch.cat([sd[a + ".query.weight"], sd[a + ".key.weight"], sd[a + ".value.weight"]], 0)
+            qkv_b = torch.cat([sd[a + ".query.bias"], sd[a + ".key.bias"], sd[a + ".value.bias"]], 0)
+            self.layers.append(dict(
+                qkv=self._linear(qkv_w, qkv_b),
+                out=self._linear(sd[p + ".attention.output.dense.weight"], sd[p + ".attention.output.dense.bias"]),
+                ln1=self._ln_pair(sd, p + ".attention.output.LayerNorm"),
+                fc1=self._linear(sd[p + ".intermediate.dense.weight"], sd[p + ".intermediate.dense.bias"]),
+                fc2=self._linear(sd[p + ".output.dense.weight"], sd[p + ".output.dense.bias"]),
+                ln2=self._ln_pair(sd, p + ".output.LayerNorm")))
+
+    def _plan(self, B: int, T: int, slot: int = 0):
+        key = (slot, B, T)
+        if key in self._cache:
+            return self._cache[key]
+        geo, dev = self.geo, self.device
+        D, Fd, M = geo.hidden, geo.ffn, B * T
+        pl = dict(B=B, T=T, M=M)
+        pl["frame_offs_host"] = [b * T for b in range(B + 1)]
+        pl["frame_offs"] = torch.tensor(pl["frame_offs_host"], dtype=torch.int32, device=dev)
+        pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
+        pl["xa"], pl["ha"] = self._new_act(M, D), self._new_act(M, D)
+        pl["qkv"], pl["ctx"], pl["ffn"] = self._new_act(M, 3 * D), self._new_act(M, D), self._new_act(M, Fd)
+        pl["tmp"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        if len(self._cache) >= 4:
+            self._cache.pop(next(iter(self._cache)))
+        self._cache[key] = pl
+        return pl
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, slot: int = 0) -> HiddenStates:
+        """``model(input_ids, attention_mask, output_hidden_states=True).hidden_states`` (preprocess_roberta.py:57,68)."""
+        geo = self.geo
+        B, T = input_ids.shape
+        if attention_mask.shape != input_ids.shape:
+            raise ValueError("attention_mask must have the shape of input_ids")
+        mask = attention_mask.to(torch.int64).cpu()
+        klen = mask.sum(dim=1)
+        if not torch.equal(mask, (torch.arange(T)[None, :] < klen[:, None]).to(torch.int64)) or int(klen.min()) < 1:
+            raise ValueError("attention_mask must be right-padded with at least one valid token per sequence")
+        ids = input_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        key_lens = klen.to(device=self.device, dtype=torch.int32)
+        return self.forward_device(ids, key_lens, slot)
+
+    def forward_device(self, ids: torch.Tensor, key_lens: torch.Tensor, slot: int = 0) -> HiddenStates:
+        """Same as ``forward`` with inputs already on the device (int32 ids [B,T], int32 key lengths [B]):
+        no host synchronisation, so it can be captured into a hipGraph."""
+        geo = self.geo
+        B, T = ids.shape
+        pl = self._plan(B, T, slot)
+        M, D = pl["M"], geo.hidden
+        states = pl["states"]
+        xa = pl["xa"]
+        check(lib.ser_embed_ln(ids.data_ptr(), self.wemb.data_ptr(), self.pemb.data_ptr(), self.temb.data_ptr(),
+                               self.emb_ln[0].data_ptr(), self.emb_ln[1].data_ptr(), float(geo.layer_norm_eps),
+                               states[0].data_ptr(), xa.ptr, xa.plane_stride, self.mode, B, T, D, geo.pad_token_id,
+                               _stream()), "ser_embed_ln")
+        scale = geo.head_dim ** -0.5 * 1.4426950408889634
+        for i, lay in enumerate(self.layers):
+            x = states[i]
+            self._gemm(xa, lay["qkv"], M, out_act=pl["qkv"], col_scale=scale, col_scale_end=D)
+            self._attention(pl["qkv"], pl["frame_offs"], B, T, pl["ctx"], key_lens=key_lens)
+            self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["tmp"], ldo_f32=D)
+            self._layernorm(pl["tmp"], D, lay["ln1"], M, D, out_f32=pl["h"], out_act=pl["ha"])
+            self._gemm(pl["ha"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
+            self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=pl["tmp"], ldo_f32=D)
+            self._layernorm(pl["tmp"], D, lay["ln2"], M, D, out_f32=states[i + 1], out_act=xa)
+        return HiddenStates(states, pl["frame_offs_host"])
+
+
 def mean_last4(hs: HiddenStates) -> torch.Tensor:
     """``--use_average y``: mean of the last four states (preprocess_speech.py:52-63), on the GPU."""
     s = hs.states
@@ -644,6 +733,8 @@ def mean_last4(hs: HiddenStates) -> torch.Tensor:
 
 
 def build_encoder(geo: EncoderGeometry, state_dict, device="cuda:0", mode="bf16"):
+    if geo.family == FAMILY_ROBERTA:
+        return TextEncoder(geo, state_dict, device, mode)
     if geo.family == FAMILY_WHISPER:
         return WhisperEncoder(geo, state_dict, device, mode)
     return SpeechEncoder(geo, state_dict, device, mode)

@@ -21,7 +21,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from .config import EncoderGeometry, FAMILY_WAVLM, FAMILY_WHISPER
+from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
 StateDict = Dict[str, torch.Tensor]
 
@@ -62,6 +62,22 @@ def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
     r = _Rng(seed)
     sd: StateDict = {}
     D, H, Fd, dh = geo.hidden, geo.heads, geo.ffn, geo.head_dim
+    if geo.family == FAMILY_ROBERTA:
+        sd["embeddings.word_embeddings.weight"] = r.normal(geo.vocab_size, D, std=0.5)
+        sd["embeddings.position_embeddings.weight"] = r.normal(geo.max_positions, D, std=0.3)
+        sd["embeddings.token_type_embeddings.weight"] = r.normal(geo.type_vocab_size, D, std=0.2)
+        _layer_norm(sd, r, "embeddings.LayerNorm", D)
+        for i in range(geo.num_layers):
+            p = f"encoder.layer.{i}"
+            _linear(sd, r, p + ".attention.self.query", D, D, gain=1.6)
+            _linear(sd, r, p + ".attention.self.key", D, D, gain=1.6)
+            _linear(sd, r, p + ".attention.self.value", D, D)
+            _linear(sd, r, p + ".attention.output.dense", D, D)
+            _layer_norm(sd, r, p + ".attention.output.LayerNorm", D)
+            _linear(sd, r, p + ".intermediate.dense", Fd, D)
+            _linear(sd, r, p + ".output.dense", D, Fd)
+            _layer_norm(sd, r, p + ".output.LayerNorm", D)
+        return sd
     if geo.family == FAMILY_WHISPER:
         sd["encoder.conv1.weight"] = r.normal(D, geo.n_mels, 3, std=math.sqrt(2.0 / (geo.n_mels * 3)))
         sd["encoder.conv1.bias"] = r.normal(D, std=0.05)
@@ -121,7 +137,7 @@ def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
     return sd
 
 
-_STRIP_PREFIXES = ("wavlm.", "wav2vec2.", "hubert.", "model.")
+_STRIP_PREFIXES = ("wavlm.", "wav2vec2.", "hubert.", "model.", "roberta.")
 
 
 def normalize_names(sd: StateDict) -> StateDict:
@@ -134,7 +150,8 @@ def normalize_names(sd: StateDict) -> StateDict:
             if k.startswith(p):
                 k = k[len(p):]
                 break
-        if k.startswith(("decoder.", "lm_head", "proj_out", "quantizer", "project_", "masked_spec_embed")):
+        if k.startswith(("decoder.", "lm_head", "proj_out", "quantizer", "project_", "masked_spec_embed", "pooler.",
+                         "embeddings.position_ids")):
             continue
         out[k] = v.detach().to(torch.float32).contiguous()
     return out

@@ -140,6 +140,39 @@ def whisper_case(tag, geo, seed, lengths):
     np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **rec)
 
 
+def roberta_case(tag, geo, seed):
+    import transformers as tf
+    sd = synthetic_state_dict(geo, seed)
+    cfg = tf.RobertaConfig(vocab_size=geo.vocab_size, hidden_size=geo.hidden, num_hidden_layers=geo.num_layers,
+                           num_attention_heads=geo.heads, intermediate_size=geo.ffn, hidden_act="gelu",
+                           max_position_embeddings=geo.max_positions, type_vocab_size=geo.type_vocab_size,
+                           layer_norm_eps=geo.layer_norm_eps, pad_token_id=geo.pad_token_id, bos_token_id=0, eos_token_id=2)
+    model = tf.RobertaModel(cfg, add_pooling_layer=False).eval()
+    load_into(model, sd)
+    max_len = 80
+    rng = np.random.default_rng(seed)
+    rec = {"seed": seed, "digest": state_dict_digest(sd), "max_len": np.array(max_len)}
+    worst = 0.0
+    for j, n in enumerate((80, 37, 5)):                       # full, padded, almost empty (tokenizer padding="max_length")
+        ids = np.full(max_len, geo.pad_token_id, dtype=np.int64)
+        ids[:n] = rng.integers(3, geo.vocab_size, n)
+        ids[0], ids[n - 1] = 0, 2
+        mask = (np.arange(max_len) < n).astype(np.int64)
+        with torch.no_grad():
+            out = model(input_ids=torch.from_numpy(ids)[None], attention_mask=torch.from_numpy(mask)[None],
+                        output_hidden_states=True)             # preprocess_roberta.py:57,68
+        hs = [h.squeeze(0) for h in out.hidden_states]
+        assert torch.equal(hs[-1], out.last_hidden_state.squeeze(0))
+        ours = O.roberta_hidden_states(geo, sd, torch.from_numpy(ids), torch.from_numpy(mask))
+        for a, b in zip(ours, hs):
+            worst = max(worst, float((a - b).abs().max() / max(1.0, float(b.abs().max()))))
+        rec[f"ids_{j}"], rec[f"mask_{j}"] = ids, mask
+        rec[f"states_{j}"] = torch.stack(hs).numpy().astype(np.float32)
+    print(f"{tag}: oracle vs HF rel-max err {worst:.2e}")
+    assert worst < 2e-5, worst
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **rec)
+
+
 def integer_tables():
     import transformers as tf
     geo = C.WAVLM_LARGE
@@ -194,12 +227,16 @@ def full_size_pins():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "roberta":       # add the text fixture without touching the others
+        roberta_case("tiny_roberta_d128h2", C.TINY_ROBERTA, 15)
+        return
     integer_tables()
     ragged = [16000, 23457]
     speech_case("tiny_wavlm_d128h2", C.TINY_WAVLM, 11, ragged)
     speech_case("tiny_wav2vec2_d960h8", C.TINY_WAV2VEC2, 12, ragged)
     speech_case("tiny_hubert_d320h4", C.TINY_HUBERT, 13, ragged)
     whisper_case("tiny_whisper_d128h2", C.TINY_WHISPER, 14, [16000, 100000])
+    roberta_case("tiny_roberta_d128h2", C.TINY_ROBERTA, 15)
     full_size_pins()
 
 

@@ -294,6 +294,45 @@ def whisper_hidden_states(geo, sd: StateDict, input_features: Tensor) -> List[Te
     return states
 
 
+# --------------------------------------------------------- next row 8f-1: RoBERTa text
+def roberta_position_ids(input_ids: Tensor, pad_token_id: int) -> Tensor:
+    """cumsum over non-pad tokens, offset by padding_idx; pads keep padding_idx
+    (HF modeling_roberta.py:142-155)."""
+    mask = (input_ids != pad_token_id).to(torch.long)
+    return torch.cumsum(mask, dim=-1) * mask + pad_token_id
+
+
+def roberta_hidden_states(geo, sd: StateDict, input_ids: Tensor, attention_mask: Tensor) -> List[Tensor]:
+    """[T] token ids + [T] 0/1 mask -> L+1 states [T, D]: embeddings (word + position + token-type -> LayerNorm)
+    then L post-LayerNorm BERT layers; padded KEYS are masked, padded QUERY rows are still computed and saved
+    (preprocessing/preprocess_roberta.py:47-69 keeps all max_len rows; HF modeling_roberta.py:56-120, 158-420)."""
+    eps = geo.layer_norm_eps
+    H, dh = geo.heads, geo.head_dim
+    pos = roberta_position_ids(input_ids, geo.pad_token_id)
+    h = (sd["embeddings.word_embeddings.weight"][input_ids] + sd["embeddings.position_embeddings.weight"][pos]
+         + sd["embeddings.token_type_embeddings.weight"][0])
+    h = _ln(h, sd, "embeddings.LayerNorm", eps)
+    T = h.shape[0]
+    neg = torch.zeros(T)
+    neg[attention_mask == 0] = float("-inf")
+    states = [h]
+    for i in range(geo.num_layers):
+        p = f"encoder.layer.{i}"
+        a = p + ".attention.self"
+        q = _heads(F.linear(h, sd[a + ".query.weight"], sd[a + ".query.bias"]), H)
+        k = _heads(F.linear(h, sd[a + ".key.weight"], sd[a + ".key.bias"]), H)
+        v = _heads(F.linear(h, sd[a + ".value.weight"], sd[a + ".value.bias"]), H)
+        scores = torch.matmul(q, k.transpose(1, 2)) * (dh ** -0.5) + neg[None, None, :]
+        ctx = torch.matmul(torch.softmax(scores, dim=-1), v).permute(1, 0, 2).reshape(T, H * dh)
+        h = _ln(h + F.linear(ctx, sd[p + ".attention.output.dense.weight"], sd[p + ".attention.output.dense.bias"]),
+                sd, p + ".attention.output.LayerNorm", eps)
+        f = F.linear(F.gelu(F.linear(h, sd[p + ".intermediate.dense.weight"], sd[p + ".intermediate.dense.bias"])),
+                     sd[p + ".output.dense.weight"], sd[p + ".output.dense.bias"])
+        h = _ln(h + f, sd, p + ".output.LayerNorm", eps)
+        states.append(h)
+    return states
+
+
 # ----------------------------------------------------------------------- a19/a20
 def select_state(states: Sequence[Tensor], layer_index: int, use_average: bool) -> Tensor:
     """``--use_average y`` -> mean of the last four states, else states[index]

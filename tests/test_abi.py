@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_binding_covers_header(built_library):
     from interspeech_ser_amd import _lib
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
-    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 6
 
 
 def test_gemm_args_layout_matches_c(built_library, tmp_path):
@@ -52,7 +52,7 @@ def test_argument_errors_are_reported_not_raised(built_library):
     assert _lib.lib.ser_gemm(ctypes.byref(g), None) < 0
     assert b"ser_gemm" in _lib.lib.ser_last_error()
     assert _lib.lib.ser_layernorm(None, 0, None, None, 1e-5, 0, None, 0, None, 0, 0, 1, 1, 8, None) < 0
-    assert _lib.lib.ser_attention(None, 0, 0, 0, 0, 0, None, 1, 1, None, 0, None, None, 0, 0, 1, 64, 0.125, 1, 0, None, None) < 0
+    assert _lib.lib.ser_attention(None, 0, 0, 0, 0, 0, None, 1, 1, None, 0, None, None, 0, 0, 1, 64, 0.125, 1, 0, None, None, None) < 0
     assert _lib.lib.ser_workspace_bytes(_lib.WS_LOGMEL, 4, 0, 0, 0, 1) == 4 * 256 + 400 * 201 * 16
 
 

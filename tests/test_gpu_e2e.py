@@ -106,6 +106,69 @@ def test_whisper_golden(golden_dir, mode):
     assert worst < TOL[mode], worst
 
 
+@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+def test_roberta_golden(golden_dir, mode):
+    """Next row 8f-1: text encoder states (all 80 rows, padded keys masked) vs the HF fixture."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import TextEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict, state_dict_digest
+    geo = C.TINY_ROBERTA
+    gold = np.load(os.path.join(golden_dir, "tiny_roberta_d128h2.npz"))
+    sd = synthetic_state_dict(geo, int(gold["seed"]))
+    assert state_dict_digest(sd) == str(gold["digest"])
+    ids = torch.from_numpy(np.stack([gold[f"ids_{j}"] for j in range(3)]))
+    mask = torch.from_numpy(np.stack([gold[f"mask_{j}"] for j in range(3)]))
+    enc = TextEncoder(geo, sd, "cuda:0", mode=mode)
+    hs = enc.forward(ids, mask)
+    torch.cuda.synchronize()
+    assert len(hs) == geo.num_layers + 1
+    worst = 0.0
+    for j in range(3):
+        ref = torch.from_numpy(gold[f"states_{j}"])
+        assert hs.frames(j) == 80
+        for layer in range(ref.shape[0]):
+            worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
+    print(f"roberta {mode}: worst rel err {worst:.3e}")
+    assert worst < TOL[mode], worst
+
+
+def test_roberta_driver_files(tmp_path, capsys):
+    """preprocess_roberta.py counterpart end to end with a stand-in tokenizer (vocab files are not available offline)."""
+    import pandas as pd
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    df = pd.DataFrame({"FileName": ["a_0001.wav", "b_0002.wav", "c_0003.wav"],
+                       "transcription": ["hello there", "a much longer sentence with several more words in it", "ok"]})
+    csv = tmp_path / "t.csv"
+    df.to_csv(csv, index=False)
+    max_len = 80
+
+    def fake_tokenize(texts):
+        ids = torch.full((len(texts), max_len), 1, dtype=torch.int64)
+        mask = torch.zeros((len(texts), max_len), dtype=torch.int64)
+        for i, t in enumerate(texts):
+            toks = [0] + [3 + (hash(w) % 40000) for w in t.split()][: max_len - 2] + [2]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return ids, mask
+
+    out = tmp_path / "feats"
+    rc = driver.run_roberta(["--roberta_type", "roberta-large", "--df_path", str(csv), "--save_path", str(out),
+                             "--synthetic_weights", "--max_len", "80"], tokenize=fake_tokenize)
+    assert rc == 0, capsys.readouterr().out
+    assert sorted(os.listdir(out)) == ["a_0001.pt", "b_0002.pt", "c_0003.pt"]
+    got = torch.load(out / "b_0002.pt")
+    assert tuple(got.shape) == (80, 1024) and got.dtype == torch.float32
+    geo = C.ROBERTA_LARGE
+    sd = synthetic_state_dict(geo, 7)
+    ids, mask = fake_tokenize(["a much longer sentence with several more words in it"])
+    with torch.no_grad():
+        ref = O.roberta_hidden_states(geo, sd, ids[0], mask[0])[-1]
+    assert rel_err(got, ref) < 1e-3
+
+
 def test_mean_last4_matches_reference_rule():
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import SpeechEncoder, mean_last4

@@ -461,7 +461,7 @@ def test_attention(L, mode, dh, H, bias):
     gd = gate.to(DEV) if bias else None
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
                                 td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
-                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, stream()))
+                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, None, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < (3e-2 if mode == 1 else 1e-4), err
@@ -497,7 +497,7 @@ def test_attention_fused_gate_columns(L, mode):
     foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
     td, cd = table.to(DEV), cst.to(DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), ld, M * ld, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax, td.data_ptr(), Tmax,
-                                None, out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 3 * D, cd.data_ptr(), stream()))
+                                None, out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 3 * D, cd.data_ptr(), None, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < (3e-2 if mode == 1 else 1e-4), err
@@ -537,7 +537,7 @@ def test_attention_prescaled_q(L, mode, dh, bias):
     gd = gate.to(DEV) if bias else None
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
                                 td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
-                                out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, stream()))
+                                out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, None, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < (3e-2 if mode == 1 else 1e-4), err
@@ -561,6 +561,58 @@ def test_gemm_column_scale(L):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_key_lengths(L, mode):
+    """Text encoders: every sequence keeps all T query rows, keys >= key_lens[b] are padding."""
+    T, B, H, dh = 80, 3, 2, 64
+    D, M = H * dh, B * T
+    klens = [80, 37, 5]
+    g = torch.Generator().manual_seed(8)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    qa = to_act(qkv, mode)
+    qv = act_value(qa).cpu().double()
+    ref = torch.empty(M, D, dtype=torch.float64)
+    for b in range(B):
+        blk = qv[b * T:(b + 1) * T]
+        q, k, v = (blk[:, i * D:(i + 1) * D].view(T, H, dh).permute(1, 0, 2) for i in range(3))
+        s = torch.matmul(q, k.transpose(1, 2)) * dh ** -0.5
+        s[:, :, klens[b]:] = float("-inf")
+        ref[b * T:(b + 1) * T] = torch.matmul(torch.softmax(s, -1), v).permute(1, 0, 2).reshape(T, D)
+    planes = 2 if mode == 2 else 1
+    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    foffs = torch.arange(0, M + 1, T, dtype=torch.int32, device=DEV)
+    kl = torch.tensor(klens, dtype=torch.int32, device=DEV)
+    L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), B, T, None, 0, None,
+                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, kl.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < (3e-2 if mode == 1 else 1e-4), err
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_embed_ln(L, mode):
+    B, T, D, V, pad = 3, 20, 128, 50, 1
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(2, V, (B, T), generator=g)
+    ids[1, 12:] = pad
+    ids[2, 3:] = pad
+    w, pe, te = torch.randn(V, D, generator=g), torch.randn(T + 2, D, generator=g), torch.randn(D, generator=g)
+    lw, lb = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    m = (ids != pad).long()
+    pos = torch.cumsum(m, 1) * m + pad
+    ref = torch.nn.functional.layer_norm((w[ids] + pe[pos] + te).double(), (D,), lw.double(), lb.double(), 1e-5).view(B * T, D)
+    idd = ids.to(torch.int32).to(DEV)
+    of = torch.empty(B * T, D, device=DEV)
+    planes = 2 if mode == 2 else 1
+    oa = torch.empty(planes, B * T, D, dtype=torch.bfloat16, device=DEV)
+    wd, ped, ted, lwd, lbd = (t.to(DEV) for t in (w, pe, te, lw, lb))
+    L.check(L.lib.ser_embed_ln(idd.data_ptr(), wd.data_ptr(), ped.data_ptr(), ted.data_ptr(), lwd.data_ptr(), lbd.data_ptr(),
+                               1e-5, of.data_ptr(), oa.data_ptr(), B * T * D, mode, B, T, D, pad, stream()))
+    torch.cuda.synchronize()
+    assert (of.cpu().double() - ref).abs().max().item() < 2e-5
+    assert (act_value(oa).cpu().double() - ref).abs().max().item() < (4e-2 if mode == 1 else 1e-4)
+
+
 def test_attention_online_softmax_rescale(L):
     """A key in a late tile dominates: forces the running-max rescale branch (one spike per head)."""
     T, H, dh = 300, 1, 64
@@ -574,7 +626,7 @@ def test_attention_online_softmax_rescale(L):
     out = torch.zeros(2, T, dh, dtype=torch.bfloat16, device=DEV)
     foffs = torch.tensor([0, T], dtype=torch.int32, device=DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * dh, T * 3 * dh, 0, dh, 2 * dh, foffs.data_ptr(), 1, T, None, 0, None,
-                                out.data_ptr(), dh, T * dh, H, dh, dh ** -0.5, 2, 0, None, stream()))
+                                out.data_ptr(), dh, T * dh, H, dh, dh ** -0.5, 2, 0, None, None, stream()))
     torch.cuda.synchronize()
     assert (act_value(out).cpu().double() - ref).abs().max().item() < 1e-4
 
