@@ -128,7 +128,7 @@ class _Extractor:
         hs = self.enc.forward(self.enc.upload(waves), lengths)
         sel = mean_last4(hs) if self.average else hs.states[layer_index]
         out = []
-        host = sel.to("cpu", non_blocking=False)
+        host = self.enc.download(sel)
         for b, n in enumerate(lengths):
             rows = host[hs.frame_offs[b]: hs.frame_offs[b + 1]]
             if self.whisper:

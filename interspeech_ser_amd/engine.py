@@ -476,15 +476,34 @@ class SpeechEncoder(_EncoderBase):
 
     # ------------------------------------------------------------------ forward
     def upload(self, waves: Sequence[np.ndarray]) -> torch.Tensor:
-        """Pack raw fp32 waveforms into one pinned host buffer and copy H2D."""
+        """Pack raw fp32 waveforms into a (reused, grow-only) pinned host buffer and copy H2D.
+        The copy is enqueued on the current stream; the staging buffer is reused only after an event
+        recorded behind the previous copy has completed."""
         total = int(sum(len(w) for w in waves))
-        host = torch.empty(total, dtype=torch.float32).pin_memory()
+        pin = getattr(self, "_pin_in", None)
+        if pin is None or pin.numel() < total:
+            pin = torch.empty(max(total, 1 << 20), dtype=torch.float32).pin_memory()
+            self._pin_in, self._pin_in_evt = pin, None
+        elif self._pin_in_evt is not None:
+            self._pin_in_evt.synchronize()
+        host = pin[:total]
+        view = host.numpy()
         o = 0
         for w in waves:
             n = len(w)
-            host[o:o + n] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+            view[o:o + n] = w
             o += n
-        return host.to(self.device, non_blocking=True)
+        dev = host.to(self.device, non_blocking=True)
+        self._pin_in_evt = torch.cuda.Event()
+        self._pin_in_evt.record()
+        return dev
+
+    def download(self, t: torch.Tensor) -> torch.Tensor:
+        """Device fp32 tensor -> fresh pinned host tensor (async D2H + one synchronisation)."""
+        host = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return host
 
     def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
         """packed raw samples [sum(lengths)] fp32 on the device -> L+1 hidden states."""
@@ -598,6 +617,7 @@ class WhisperEncoder(_EncoderBase):
         return pl
 
     upload = SpeechEncoder.upload
+    download = SpeechEncoder.download
 
     def log_mel(self, packed_wave: torch.Tensor, lengths: Sequence[int]) -> torch.Tensor:
         """a16: [B, n_mels, 3000] fp32 input_features, computed on the GPU."""

@@ -126,3 +126,20 @@ def test_synthetic_weights_have_hf_names_and_shapes():
     wrapped = {"wav2vec2." + k: v for k, v in sd2.items()}
     wrapped["lm_head.weight"] = torch.zeros(2, 2)
     assert sorted(normalize_names(wrapped)) == sorted(sd2)
+
+
+def test_checkpoint_round_trip_with_hub_prefixes(tmp_path):
+    """A hub-style checkpoint (task-head prefix, extra heads, safetensors) loads to the bare encoder names."""
+    from safetensors.torch import save_file
+    from interspeech_ser_amd.weights import load_checkpoint, state_dict_digest, synthetic_state_dict
+    sd = synthetic_state_dict(C.TINY_WAVLM, 3)
+    hub = {"wavlm." + k: v.clone() for k, v in sd.items()}
+    hub["wavlm.masked_spec_embed"] = torch.zeros(128)
+    hub["lm_head.weight"] = torch.zeros(4, 128)
+    d = tmp_path / "snap"
+    d.mkdir()
+    save_file(hub, str(d / "model.safetensors"))
+    back = load_checkpoint(str(d))
+    assert sorted(back) == sorted(sd) and state_dict_digest(back) == state_dict_digest(sd)
+    with pytest.raises(OSError):
+        load_checkpoint(str(tmp_path / "nothing_here"))
