@@ -53,11 +53,14 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr int CH = BK / 8;                    // 16-byte chunks per LDS row
     constexpr int ROWB = BK * 2;                  // bytes per LDS row
     constexpr int RPP = 1024 / ROWB;              // rows per 1-KiB DMA piece (one wave instruction)
-    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+    // FP32X: both planes (hi, lo) of the A and W tiles of a K tile sit in one stage, fetched ONCE, and every
+    // fragment pair feeds 3 MFMAs (hi*hi, lo*hi, hi*lo): 2x the L2->LDS bytes of bf16 for 3x the products,
+    // instead of three full passes over K
+    constexpr int NPL = (MODE == SER_MODE_FP32X) ? 2 : 1;
+    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = NPL * (A_BYTES + W_BYTES);
     constexpr int LA = BM / RPP / NW, LW = BN / RPP / NW;       // DMA pieces per wave per K tile
-    constexpr int LPT = LA + LW;
+    constexpr int LPT = NPL * (LA + LW);
     constexpr int KS = BK / 32;                   // MFMA k-steps per K tile
-    constexpr int NSEG = (MODE == SER_MODE_FP32X) ? 3 : 1;
     static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile/wave mismatch");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -110,25 +113,28 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     }
 
     const int nk = p.K / BK;
-    const int total = nk * NSEG;
+    const int total = nk;
     const int tpc = p.kc ? p.kc / BK : 0x7fffffff;                                // K tiles per conv chunk
 
-    int i_kk = 0, i_cc = 0, i_cj = 0, i_seg = 0, i_stage = 0;                    // issue-side scalar state
+    int i_kk = 0, i_cc = 0, i_cj = 0, i_stage = 0;                               // issue-side scalar state
     auto issue = [&]() {
-        const int64_t koffA = (int64_t)i_cj * p.ldj + (int64_t)i_cc * BK
-                            + ((NSEG == 3 && i_seg == 1) ? p.a_plane_stride : 0);
-        const int64_t koffW = (int64_t)i_kk * BK + ((NSEG == 3 && i_seg == 2) ? p.w_plane_stride : 0);
-        char* dstA = lds + i_stage * STAGE + wave * 1024;
-        char* dstW = dstA + A_BYTES;
+        const int64_t koffA = (int64_t)i_cj * p.ldj + (int64_t)i_cc * BK;
+        const int64_t koffW = (int64_t)i_kk * BK;
+        char* dstA = lds + i_stage * STAGE + wave * 1024;        // stage = [A hi][A lo][W hi][W lo]
+        char* dstW = dstA + NPL * A_BYTES;
 #pragma unroll
-        for (int q = 0; q < LA; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[q] + koffA), (lptr_t)(dstA + q * NW * 1024), 16, 0, 0);
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-        for (int q = 0; q < LW; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[q] + koffW), (lptr_t)(dstW + q * NW * 1024), 16, 0, 0);
+            for (int q = 0; q < LA; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(aptr[q] + koffA + pl * p.a_plane_stride),
+                                                 (lptr_t)(dstA + pl * A_BYTES + q * NW * 1024), 16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < LW; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wptr[q] + koffW + pl * p.w_plane_stride),
+                                                 (lptr_t)(dstW + pl * W_BYTES + q * NW * 1024), 16, 0, 0);
+        }
         ++i_kk; ++i_cc;
         if (i_cc == tpc) { i_cc = 0; ++i_cj; }
-        if (i_kk == nk) { i_kk = 0; i_cc = 0; i_cj = 0; ++i_seg; }
         i_stage = (i_stage + 1 == ST) ? 0 : i_stage + 1;
     };
 
@@ -146,7 +152,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     for (int s = 0; s < KS; ++s) {
         const int phys = ((s * 4 + fq) ^ fsw) << 4;
         offA[s] = (wm * TM * 16 + frow) * ROWB + phys;
-        offW[s] = A_BYTES + (wn * TN * 16 + frow) * ROWB + phys;
+        offW[s] = NPL * A_BYTES + (wn * TN * 16 + frow) * ROWB + phys;
     }
 
     constexpr int CPL = TN * 4;
@@ -215,35 +221,63 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         if (kt + ST - 1 < total) issue();           // refills the stage every wave finished reading before the barrier
         const char* sb = lds + c_stage * STAGE;
         c_stage = (c_stage + 1 == ST) ? 0 : c_stage + 1;
-        // all k-steps' fragments are requested up front: the LDS reads of step s+1 complete under the
-        // MFMAs of step s (the compiler places counted lgkmcnt waits between the clusters)
-        // (PIPE; the 128x64-per-wave configuration has no registers to spare and loads per step)
-        constexpr bool PIPE = (TM * TN * 4 + KS * (TM + TN) * 4) <= 208;
-        bf16x8 af[KS][TM], wf[KS][TN];
-        if constexpr (PIPE) {
+        if constexpr (NPL == 1) {
+            // all k-steps' fragments are requested up front: the LDS reads of step s+1 complete under the
+            // MFMAs of step s (the compiler places counted lgkmcnt waits between the clusters)
+            // (PIPE; the 128x64-per-wave configuration has no registers to spare and loads per step)
+            constexpr bool PIPE = (TM * TN * 4 + KS * (TM + TN) * 4) <= 208;
+            bf16x8 af[KS][TM], wf[KS][TN];
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                    for (int x = 0; x < TM; ++x) af[s][x] = *(const bf16x8*)(sb + offA[s] + x * 16 * ROWB);
+#pragma unroll
+                    for (int x = 0; x < TN; ++x) wf[s][x] = *(const bf16x8*)(sb + offW[s] + x * 16 * ROWB);
+                }
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
+                if constexpr (!PIPE) {
 #pragma unroll
-                for (int x = 0; x < TM; ++x) af[s][x] = *(const bf16x8*)(sb + offA[s] + x * 16 * ROWB);
+                    for (int x = 0; x < TM; ++x) af[s][x] = *(const bf16x8*)(sb + offA[s] + x * 16 * ROWB);
 #pragma unroll
-                for (int x = 0; x < TN; ++x) wf[s][x] = *(const bf16x8*)(sb + offW[s] + x * 16 * ROWB);
+                    for (int x = 0; x < TN; ++x) wf[s][x] = *(const bf16x8*)(sb + offW[s] + x * 16 * ROWB);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][ni], af[s][mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
-        }
+        } else {
+            // FP32X: 4 fragment sets per k-step, 3 products per (weight, activation) sub-tile pair
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if constexpr (!PIPE) {
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
-                for (int x = 0; x < TM; ++x) af[s][x] = *(const bf16x8*)(sb + offA[s] + x * 16 * ROWB);
+                for (int x = 0; x < TM; ++x) {
+                    ah[x] = *(const bf16x8*)(sb + offA[s] + x * 16 * ROWB);
+                    al[x] = *(const bf16x8*)(sb + offA[s] + A_BYTES + x * 16 * ROWB);
+                }
 #pragma unroll
-                for (int x = 0; x < TN; ++x) wf[s][x] = *(const bf16x8*)(sb + offW[s] + x * 16 * ROWB);
+                for (int x = 0; x < TN; ++x) {
+                    wh[x] = *(const bf16x8*)(sb + offW[s] + x * 16 * ROWB);
+                    wl[x] = *(const bf16x8*)(sb + offW[s] + W_BYTES + x * 16 * ROWB);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
             }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][ni], af[s][mi], acc[ni][mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -398,7 +432,8 @@ enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3 };
 template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI>
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int LDS = ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8);   // ring (+ [BM][2] row statistics)
+    const int npl = (a->mode == SER_MODE_FP32X) ? 2 : 1;
+    const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8);   // ring (+ [BM][2] row statistics)
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     if (a->mode == SER_MODE_BF16) {
@@ -462,10 +497,15 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
     if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
     hipStream_t s = (hipStream_t)stream;
+    if (a->mode == SER_MODE_FP32X) {
+        // both planes share a stage: the ring doubles, so FP32X uses the two configurations that still fit 160 KiB
+        if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true>(a, s);
+        return launch_cfg<4, 2, 2, 4, 64, 2, false>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
+    }
     switch (pick_cfg(a)) {
         case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 64, 2, true>(a, s);     // 160 KiB ring, one barrier per 64-deep K tile
         case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
         case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
-        default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
+        default:          return launch_cfg<4, 2, 2, 4, 64, 2, false>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
     }
 }
