@@ -506,6 +506,6 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 64, 2, true>(a, s);     // 160 KiB ring, one barrier per 64-deep K tile
         case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
         case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
-        default:          return launch_cfg<4, 2, 2, 4, 64, 2, false>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
+        default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
     }
 }
