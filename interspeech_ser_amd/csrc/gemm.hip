@@ -24,6 +24,7 @@
 //   * blockIdx.x -> tile through a bijective XCD swizzle so each of the 8 L2s sees a contiguous run
 //     of tiles that share activation panels.
 #include "ser_common.h"
+#include <stdlib.h>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -464,8 +465,14 @@ static int pick_cfg(const ser_gemm_args* a) {
     // Measured on MI355X (tools/gemm_sweep.py, M = 7984): the simple ring keeps the 128x128 tile
     // (2 blocks/CU) ahead of 256x128 on every N <= 3072 shape; 256x256 wins once it has >= ~2 full
     // rounds of blocks (N = 4096, conv layers) because it halves the L2->LDS bytes per FLOP.
+    // In the real step (two utterance groups in flight) 256x256 already pays from ~200 tiles (QKV and FC1
+    // at M = 3992): 9.6 -> 9.1 ms per step, A/B on one device.
     const long t256x256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
-    if (a->N >= 256 && t256x256 >= 448) return CFG_256x256;
+    static const long t256_min = [] {                   // tuning knob (tools/): SER_GEMM_T256_MIN=<tiles>
+        const char* e = getenv("SER_GEMM_T256_MIN");
+        return e ? atol(e) : 200L;
+    }();
+    if (a->N >= 256 && t256x256 >= t256_min) return CFG_256x256;
     return CFG_128x128;
 }
 

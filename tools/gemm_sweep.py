@@ -9,8 +9,8 @@ from interspeech_ser_amd import _lib as L
 
 DEV = "cuda:0"
 SHAPES = [  # name, M, N, K, gelu, residual, act_out
-    ("qkv", 7984, 3072, 1024, 0, 0, 1), ("out", 7984, 1024, 1024, 0, 1, 0), ("fc1", 7984, 4096, 1024, 1, 0, 1),
-    ("fc2", 7984, 1024, 4096, 0, 1, 0), ("proj", 7984, 1024, 512, 0, 0, 1),
+    ("qkv", 3992, 3104, 1024, 0, 0, 1), ("out", 3992, 1024, 1024, 0, 1, 0), ("fc1", 3992, 4096, 1024, 1, 0, 1),
+    ("fc2", 3992, 1024, 4096, 0, 1, 0), ("qkv16", 7984, 3104, 1024, 0, 0, 1), ("fc1_16", 7984, 4096, 1024, 1, 0, 1),
 ]
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 planes = 2 if mode == 2 else 1
