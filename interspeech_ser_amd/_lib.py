@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libserhip.so")
+LIB_PATH = os.environ.get("SER_HIP_LIB") or os.path.join(_HERE, "lib", "libserhip.so")   # override: A/B builds (tools/)
 
 MODE_BF16 = 1
 MODE_FP32X = 2
