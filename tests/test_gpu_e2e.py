@@ -76,6 +76,38 @@ def test_batched_equals_single(golden_dir):
             assert torch.equal(one.utterance(0, l).cpu(), batched[b][l]), (b, l)
 
 
+def test_extreme_ragged_batch_matches_oracle():
+    """One-frame utterance (400 samples), a 65-frame one (tile boundary) and a long one in ONE batch."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.TINY_WAVLM
+    sd = synthetic_state_dict(geo, 21)
+    lengths = [400, 400 + 320 * 64, 719, 50000, 401]
+    waves = [synth_wave(70 + i, n) for i, n in enumerate(lengths)]
+    enc = SpeechEncoder(geo, sd, "cuda:0", mode="fp32x")
+    hs = enc.forward(enc.upload(waves), lengths)
+    torch.cuda.synchronize()
+    assert [hs.frames(b) for b in range(len(lengths))] == [1, 65, 1, 156, 1]
+    worst = 0.0
+    for b, w in enumerate(waves):
+        ref = O.speech_hidden_states(geo, sd, torch.from_numpy(O.zero_mean_unit_var(w)))
+        for layer, r in enumerate(ref):
+            worst = max(worst, rel_err(hs.utterance(b, layer).cpu(), r))
+    assert worst < 1e-3, worst
+
+
+def test_too_short_utterance_is_rejected_cleanly():
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_WAVLM
+    enc = SpeechEncoder(geo, synthetic_state_dict(geo, 1), "cuda:0", mode="bf16")
+    with pytest.raises(ValueError):
+        enc.forward(enc.upload([np.zeros(399, dtype=np.float32)]), [399])
+
+
 @pytest.mark.parametrize("mode", ["fp32x", "bf16"])
 def test_whisper_golden(golden_dir, mode):
     from interspeech_ser_amd import config as C
