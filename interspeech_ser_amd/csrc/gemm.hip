@@ -350,7 +350,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 if (p.act == SER_ACT_GELU) {
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {
-                        const f32x2 y = gelu_erf2((f32x2){v[r], v[r + 1]});
+                        const f32x2 y = gelu2<MODE == SER_MODE_BF16>((f32x2){v[r], v[r + 1]});
                         v[r] = y[0]; v[r + 1] = y[1];
                     }
                 }
@@ -391,7 +391,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 if (p.act == SER_ACT_GELU) {
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {
-                        const f32x2 y = gelu_erf2((f32x2){v[r], v[r + 1]});
+                        const f32x2 y = gelu2<MODE == SER_MODE_BF16>((f32x2){v[r], v[r + 1]});
                         v[r] = y[0]; v[r + 1] = y[1];
                     }
                 }

@@ -50,7 +50,7 @@ __device__ __forceinline__ float erf_fast(float a) {
     q = fmaf(q, x2, -1.68282697438203e-03f);
     q = fmaf(q, x2, -7.37332916720468e-03f);
     q = fmaf(q, x2, -1.42647390514189e-02f);
-    return x * p * __frcp_rn(q);
+    return x * p * __builtin_amdgcn_rcpf(q);
 }
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
@@ -78,11 +78,35 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
     q = __builtin_elementwise_fma(q, x2, (f32x2){-7.37332916720468e-03f, -7.37332916720468e-03f});
     q = __builtin_elementwise_fma(q, x2, (f32x2){-1.42647390514189e-02f, -1.42647390514189e-02f});
     f32x2 r;
-    r[0] = __frcp_rn(q[0]);
-    r[1] = __frcp_rn(q[1]);
+    r[0] = __builtin_amdgcn_rcpf(q[0]);
+    r[1] = __builtin_amdgcn_rcpf(q[1]);
     const f32x2 e = x * p * r;                                  // erf
     const f32x2 h = v * 0.5f;
     return __builtin_elementwise_fma(h, e, h);                  // 0.5 v (1 + erf)
+}
+
+// bf16-mode GELU: [3/3] rational erf(x) ~= x P(x^2)/Q(x^2) on |x| <= 3.3 (clamped beyond: 1 - erf(3.3) = 3e-6),
+// minimax-fitted against scipy erf: |erf error| <= 3.3e-6, |gelu error| <= 8.1e-6 absolute in fp32 arithmetic -
+// two orders below the bf16 rounding of the result it feeds.  Half the Horner steps of gelu_erf2; plain (not
+// packed) fp32 ops: on gfx950 v_pk_fma_f32 issues at half rate, so packing buys nothing here.
+__device__ __forceinline__ float gelu_erf_r33(float v) {
+    const float x = __builtin_amdgcn_fmed3f(v * 0.70710678118654752440f, -3.3f, 3.3f);
+    const float u = x * x;
+    float p = 7.44480455e-04f;
+    p = fmaf(p, u, 4.31236140e-02f);
+    p = fmaf(p, u, 1.54839486e-01f);
+    p = fmaf(p, u, 1.12837927e+00f);
+    float q = 9.25275550e-03f;
+    q = fmaf(q, u, 9.49760207e-02f);
+    q = fmaf(q, u, 4.70571502e-01f);
+    q = fmaf(q, u, 1.0f);
+    const float h = 0.5f * v;
+    return fmaf(h, x * p * __builtin_amdgcn_rcpf(q), h);
+}
+template <bool FAST>
+__device__ __forceinline__ f32x2 gelu2(f32x2 v) {
+    if constexpr (FAST) return (f32x2){gelu_erf_r33(v[0]), gelu_erf_r33(v[1])};
+    else return gelu_erf2(v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
