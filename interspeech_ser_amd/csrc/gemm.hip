@@ -47,7 +47,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // WM x WN waves, each TM x TN MFMA tiles of 16x16; BK = K tile; ST = ring stages.
 template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2)
+__global__ __launch_bounds__(64 * WM * WN, 2)
 void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -105,10 +105,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         const int R = (q * NW + wave) * RPP + prow;
         const int f = (BK == 64) ? (R & 7) : ((R >> 1) & 3);
         const int c = ppos ^ f;
-        // weight-row permutation: LDS row (wcol*TN*16 + ni*16 + i) holds n = wcol*TN*16 + (i>>2)*TN*4 + ni*4 + (i&3)
-        const int wcol = R / (TN * 16), rr = R % (TN * 16);
-        const int i = rr & 15, ni = rr >> 4;
-        int n = n0 + wcol * (TN * 16) + (i >> 2) * (TN * 4) + ni * 4 + (i & 3);
+        int n = n0 + R;
         n = n < p.N ? n : p.N - 1;
         wptr[q] = Wbase + (int64_t)n * p.K + c * 8;
     }
@@ -156,8 +153,11 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         offW[s] = NPL * A_BYTES + (wn * TN * 16 + frow) * ROWB + phys;
     }
 
+    // Natural MFMA accumulator layout: acc[ni][mi][r] is row (mi*16 + frow), column (ni*16 + fq*4 + r) of the
+    // wave tile, so the four lanes of a row cover 16 consecutive columns: fp32 stores / residual loads are 64
+    // contiguous bytes per row, and the bf16 stores reach the same after one cross-row register swap.
     constexpr int CPL = TN * 4;
-    const int ncol0 = n0 + wn * (TN * 16) + fq * CPL;                 // within the group
+    const int ncol0 = n0 + wn * (TN * 16) + fq * 4;                   // column of acc[0][.][0] within the group
     const int64_t gcol = (int64_t)g * p.c_group_stride + ncol0;       // in the output matrices
     float bias[CPL];
 #pragma unroll
@@ -165,8 +165,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     if (p.bias) {
 #pragma unroll
         for (int j4 = 0; j4 < TN; ++j4)
-            if (ncol0 + j4 * 4 < p.N) {
-                const f32x4 b = *(const f32x4*)(p.bias + (int64_t)g * p.N + ncol0 + j4 * 4);
+            if (ncol0 + j4 * 16 < p.N) {
+                const f32x4 b = *(const f32x4*)(p.bias + (int64_t)g * p.N + ncol0 + j4 * 16);
                 bias[j4 * 4 + 0] = b[0]; bias[j4 * 4 + 1] = b[1]; bias[j4 * 4 + 2] = b[2]; bias[j4 * 4 + 3] = b[3];
             }
     }
@@ -178,8 +178,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     if (p.ln_colsum) {
 #pragma unroll
         for (int j4 = 0; j4 < TN; ++j4)
-            if (ncol0 + j4 * 4 < p.N) {
-                const f32x4 b = *(const f32x4*)(p.ln_colsum + ncol0 + j4 * 4);
+            if (ncol0 + j4 * 16 < p.N) {
+                const f32x4 b = *(const f32x4*)(p.ln_colsum + ncol0 + j4 * 16);
                 csum[j4 * 4 + 0] = b[0]; csum[j4 * 4 + 1] = b[1]; csum[j4 * 4 + 2] = b[2]; csum[j4 * 4 + 3] = b[3];
             }
     }
@@ -301,7 +301,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 for (int r = 0; r < 4; ++r) {
                     const float x = acc[ni][mi][r] + bias[ni * 4 + r];
                     acc[ni][mi][r] = x;
-                    if (ncol0 + ni * 4 + r < p.N) { s1 += x; s2 += x * x; }
+                    if (ncol0 + ni * 16 < p.N) { s1 += x; s2 += x * x; }
                 }
             s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -326,9 +326,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #pragma unroll
         for (int j4 = 0; j4 < TN; ++j4) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (ncol0 + j4 * 4 < p.N) {
-                a = *(const f32x4*)(p.ln_gamma + ncol0 + j4 * 4);
-                b = *(const f32x4*)(p.ln_beta + ncol0 + j4 * 4);
+            if (ncol0 + j4 * 16 < p.N) {
+                a = *(const f32x4*)(p.ln_gamma + ncol0 + j4 * 16);
+                b = *(const f32x4*)(p.ln_beta + ncol0 + j4 * 16);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lg[j4 * 4 + r] = a[r]; lb[j4 * 4 + r] = b[r]; }
@@ -339,8 +339,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             if (m >= p.M) continue;
             const int64_t orow = p.out_rowmap ? (int64_t)p.out_rowmap[m] : (int64_t)m;
 #pragma unroll
-            for (int ni = 0; ni < TN; ni += 2) {                      // 8 columns = one 16-byte act store
-                if (ncol0 + ni * 4 >= p.N) continue;                  // N % 8 == 0: a pair is valid or not as a whole
+            for (int ni = 0; ni < TN; ni += 2) {                      // fragment column blocks ni, ni+1: 4 + 4 columns
+                const bool ok0 = ncol0 + ni * 16 < p.N, ok1 = ncol0 + ni * 16 + 16 < p.N;
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -356,11 +356,14 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 }
                 if (p.out_f32) {
                     f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4) = o0;
-                    *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4 + 4) = o1;
+                    if (ok0) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 16) = o0;
+                    if (ok1) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 16 + 16) = o1;
                 }
-                if (p.out_act)
-                    store_act8<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4, p.out_plane_stride, v);
+                if (p.out_act) {
+                    const int c8 = ni * 16 + ((fq & 1) ? 12 : 0);     // after the swap this lane holds columns c8..c8+7
+                    store_act8_swap<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + c8, p.out_plane_stride,
+                                          ncol0 + c8 < p.N, v);
+                }
             }
         }
     } else {
@@ -377,15 +380,15 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
             float st1 = 0.f, st2 = 0.f;
 #pragma unroll
-            for (int ni = 0; ni < TN; ni += 2) {                      // 8 columns per step: 16-byte act stores
-                if (ncol0 + ni * 4 >= p.N) continue;                  // N % 8 == 0: a pair is valid or not as a whole
+            for (int ni = 0; ni < TN; ni += 2) {                      // fragment column blocks ni, ni+1: 4 + 4 columns
+                const bool ok0 = ncol0 + ni * 16 < p.N, ok1 = ncol0 + ni * 16 + 16 < p.N;
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int nj = ni + (r >> 2), rr = r & 3;
                     // LN(x) W^T = rstd * (x W'^T - mu * colsum(W')) + (beta W^T + b)
                     float x = fmaf(rs, acc[nj][mi][rr] - mu * csum[nj * 4 + rr], bias[nj * 4 + rr]);
-                    if (ncol0 + nj * 4 < p.col_scale_end) x *= p.col_scale;        // e.g. q *= dh^-0.5 * log2(e)
+                    if (ncol0 + nj * 16 < p.col_scale_end) x *= p.col_scale;       // e.g. q *= dh^-0.5 * log2(e)
                     v[r] = x;
                 }
                 if (p.act == SER_ACT_GELU) {
@@ -396,21 +399,32 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     }
                 }
                 if (p.residual) {
-                    const float* rp = p.residual + (int64_t)rrow * p.ldr + gcol + ni * 4;
-                    const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+                    const float* rp = p.residual + (int64_t)rrow * p.ldr + gcol + ni * 16;
+                    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+                    if (ok0) r0 = *(const f32x4*)rp;
+                    if (ok1) r1 = *(const f32x4*)(rp + 16);
                     v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
                     v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
                 }
+                if (ok0) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
-                if (p.out_f32 && ncol0 + ni * 4 >= p.f32_col_begin) {
-                    float* op = p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 4 - p.f32_col_begin;
-                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *(f32x4*)op = o0;
-                    *(f32x4*)(op + 4) = o1;
+                    for (int r = 0; r < 4; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
                 }
-                if (p.out_act)
-                    store_act8<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + ni * 4, p.out_plane_stride, v);
+                if (ok1) {
+#pragma unroll
+                    for (int r = 4; r < 8; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
+                }
+                if (p.out_f32) {
+                    float* op = p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 16 - p.f32_col_begin;
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    if (ok0 && ncol0 + ni * 16 >= p.f32_col_begin) *(f32x4*)op = o0;
+                    if (ok1 && ncol0 + ni * 16 + 16 >= p.f32_col_begin) *(f32x4*)(op + 16) = o1;
+                }
+                if (p.out_act) {
+                    const int c8 = ni * 16 + ((fq & 1) ? 12 : 0);     // after the swap this lane holds columns c8..c8+7
+                    store_act8_swap<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + c8, p.out_plane_stride,
+                                          ncol0 + c8 < p.N, v);
+                }
             }
             if (p.stat_out) {
                 // row partials over this wave's 64 columns (deterministic: one slot per 64-column group)

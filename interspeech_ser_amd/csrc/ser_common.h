@@ -159,6 +159,39 @@ __device__ __forceinline__ void store_act8(unsigned short* dst, int64_t plane, c
     }
 }
 
+// Epilogue store for the natural MFMA accumulator layout.  v[0..3] are 4 consecutive columns c..c+3 of one
+// fragment column block, v[4..7] the same lane columns of the next block (16 columns further).  Lanes l and l^16
+// (same row, lane-column groups 2j and 2j+1) trade one packed half with v_permlane16_swap_b32 so that each ends
+// up with 8 CONSECUTIVE columns: even groups keep block 0 and get c+4..c+7 from the neighbour, odd groups keep
+// block 1 and get its c-4..c-1.  16-byte stores, and the four lanes of a row write 64 contiguous bytes.
+// dst already points at this lane's 8-column run; every lane of the pair must call (ok only gates the store).
+template <int MODE>
+__device__ __forceinline__ void store_act8_swap(unsigned short* dst, int64_t plane, bool ok, const float (&v)[8]) {
+    if (MODE == SER_MODE_BF16) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf2(v[0], v[1]), pack_bf2(v[4], v[5]), false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf2(v[2], v[3]), pack_bf2(v[6], v[7]), false, false);
+        if (ok) *(u32x4*)dst = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+    } else {
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split_bf(v[i], h[i], l[i]);
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ph[i] = (unsigned)h[2 * i] | ((unsigned)h[2 * i + 1] << 16);
+            pl[i] = (unsigned)l[2 * i] | ((unsigned)l[2 * i + 1] << 16);
+        }
+        const auto h0 = __builtin_amdgcn_permlane16_swap(ph[0], ph[2], false, false);
+        const auto h1 = __builtin_amdgcn_permlane16_swap(ph[1], ph[3], false, false);
+        const auto l0 = __builtin_amdgcn_permlane16_swap(pl[0], pl[2], false, false);
+        const auto l1 = __builtin_amdgcn_permlane16_swap(pl[1], pl[3], false, false);
+        if (ok) {
+            *(u32x4*)dst = (u32x4){h0[0], h1[0], h0[1], h1[1]};
+            *(u32x4*)(dst + plane) = (u32x4){l0[0], l1[0], l0[1], l1[1]};
+        }
+    }
+}
+
 // Load 8 consecutive act elements as fp32 (hi [+ lo]).
 template <int MODE>
 __device__ __forceinline__ void load_act8(const unsigned short* src, int64_t plane, float (&v)[8]) {
