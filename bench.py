@@ -212,6 +212,15 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         trace, enc.gemm_trace = enc.gemm_trace, None
+    # Attention-block leg (north_star target: >= 30 % of the bf16 MFMA peak on packed QKV projection -> attention ->
+    # output projection): one more eager pass with one event pair per layer around exactly that sub-graph.
+    blocks = None
+    if not args.no_trace and not whisper and geo.family != C.FAMILY_ROBERTA:
+        enc.block_trace = []
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        blocks, enc.block_trace = enc.block_trace, None
 
     elapsed = D.max_over_ranks(elapsed)
 
@@ -255,6 +264,20 @@ def main():
                 "mfma_products_per_algorithmic_flop": mult,
                 "gemm_ms_per_step": round(dur_ms / args.steps, 3),
                 "measured": "HIP events around every ser_gemm launch, eager pass of the same K steps right after the timed region",
+            }
+        if blocks:
+            T = geo.frames_for(num_samples)
+            Dm, dh = geo.hidden, geo.head_dim
+            gf_block = (2.0 * T * Dm * 3 * Dm + 2.0 * T * Dm * Dm + 4.0 * T * T * Dm) / 1e9       # q,k,v + out + QK^T + PV, per utterance
+            us = sum(b[0].elapsed_time(b[1]) for b in blocks) * 1e3 / len(blocks)
+            utts = blocks[0][2]
+            ach = gf_block * utts / us * 1e3                       # GF per us -> TF/s
+            out["attention_block"] = {
+                "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                "target_frac": 0.30, "us_per_layer_call": round(us, 2), "utterances_per_launch": utts,
+                "algorithmic_gflop_per_utt_layer": round(gf_block, 3), "layer_calls": len(blocks),
+                "measured": "HIP events around QKV GEMM -> ser_attention -> out-proj GEMM of every layer, eager pass, "
+                            "one utterance group at a time (no concurrent group)",
             }
         if world == 1 and not args.no_cpu_baseline and not whisper:
             from interspeech_ser_amd.weights import synthetic_state_dict

@@ -57,7 +57,9 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
     return DHP == 64 ? (unit ^ ((key >> 1) & 1)) : (unit ^ (key & 3));
 }
 
-template <int DHP, int MODE, bool PRE>
+// TBL: a relative-position bias table is present (WavLM) -- compile-time, so the plain path carries no bias code
+// and the bias path does not zero accumulators it is about to overwrite.
+template <int DHP, int MODE, bool PRE, bool TBL>
 __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2) void attention_kernel(const AttnParams p) {
     constexpr int NP = (MODE == SER_MODE_FP32X) ? 2 : 1;
     constexpr int RS = DHP * 2;                 // LDS row bytes
@@ -134,8 +136,38 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
     const int nfull = (TK & (ABKV - 1)) ? nkt - 1 : nkt;         // tiles without key padding
     stage_load(0, padded || nfull == 0);
 
+    // ---- Q fragments: lane holds Q[q][16*ks + 8*hh + j].  Requested here, with the gate inputs, so that their
+    // latency overlaps the first K/V tile's and the bias row's instead of following them.
+    const int q = q0 + wave * 32 + l31;
+    const int qc = q < T ? q : T - 1;
+    bf16x8 qf[NP][KS];
+    {
+        const unsigned short* qrow = p.qkv + (int64_t)(row0 + qc) * p.ld + p.q_col + h * dh;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d = ks * 16 + hh * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (d < dh) v = *(const u32x4*)(qrow + pl * p.plane + d);
+                qf[pl][ks] = __builtin_bit_cast(bf16x8, v);
+            }
+    }
+    float g_in0 = 0.f, g_in1 = 0.f, g_c = 0.f;                     // raw gate inputs (consumed after the bias copy)
+    if (TBL) {
+        if (p.gate) {
+            g_in0 = p.gate[(int64_t)(row0 + qc) * p.H + h];
+        } else {
+            // gate pre-activations ride along as two extra columns per head of the packed projection
+            const unsigned short* gp = p.qkv + (int64_t)(row0 + qc) * p.ld + p.gate_col + 2 * h;
+            g_in0 = bf2f(gp[0]); g_in1 = bf2f(gp[1]);
+            if (NP == 2) { g_in0 += bf2f(gp[p.plane]); g_in1 += bf2f(gp[p.plane + 1]); }
+            g_c = p.gru_const[h];
+        }
+    }
+
     // ---- this head's bias row, 4 shifted copies: copy c [j] = table[h][(table_T-T) + j + c] -------
-    if (p.table) {
+    if (TBL) {
         // each table element is read ONCE (5 independent loads in flight per thread and pass) and
         // scattered into the 4 shifted copies; indices past 2T-1 are written as zeros (tail padding)
         const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T);
@@ -159,33 +191,15 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
         }
     }
 
-    // ---- Q fragments: lane holds Q[q][16*ks + 8*hh + j]
-    const int q = q0 + wave * 32 + l31;
-    const int qc = q < T ? q : T - 1;
-    bf16x8 qf[NP][KS];
-    {
-        const unsigned short* qrow = p.qkv + (int64_t)(row0 + qc) * p.ld + p.q_col + h * dh;
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int d = ks * 16 + hh * 8;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (d < dh) v = *(const u32x4*)(qrow + pl * p.plane + d);
-                qf[pl][ks] = __builtin_bit_cast(bf16x8, v);
-            }
-    }
     const float c1 = p.scale * LOG2E;
     float gq2 = 0.f;
-    if (p.gate) {
-        gq2 = p.gate[(int64_t)(row0 + qc) * p.H + h] * LOG2E;
-    } else if (p.gru_const) {
-        // gate pre-activations ride along as two extra columns per head of the packed projection
-        const unsigned short* gp = p.qkv + (int64_t)(row0 + qc) * p.ld + p.gate_col + 2 * h;
-        float pa = bf2f(gp[0]), pb = bf2f(gp[1]);
-        if (NP == 2) { pa += bf2f(gp[p.plane]); pb += bf2f(gp[p.plane + 1]); }
-        const float ga = 1.f / (1.f + __expf(-pa)), gb = 1.f / (1.f + __expf(-pb));
-        gq2 = (ga * (gb * p.gru_const[h] - 1.f) + 2.f) * LOG2E;
+    if (TBL) {
+        if (p.gate) {
+            gq2 = g_in0 * LOG2E;
+        } else {
+            const float ga = __builtin_amdgcn_rcpf(1.f + __expf(-g_in0)), gb = __builtin_amdgcn_rcpf(1.f + __expf(-g_in1));
+            gq2 = (ga * (gb * g_c - 1.f) + 2.f) * LOG2E;
+        }
     }
     // aligned bias window: index of key kb (multiple of 4) is kb - qc + T-1 = a + sh with a % 4 == 0
     const int bsh = (T - 1 - qc) & 3;
@@ -203,6 +217,10 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
 
     auto tile = [&](int kt, auto ragged_tag) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
+        // WIDE (bf16, head dim <= 64): every LDS read of a phase is issued before its first consumer, so a phase
+        // pays the LDS latency once; left alone, hipcc re-uses one fragment register and emits
+        // read -> wait(0) -> MFMA eight times in a row (measured: 1400 of a tile's 3600 cycles).
+        constexpr bool WIDE = (NP == 1 && DHP == 64);
         const int cur = DB ? (kt & 1) : 0;
         const char* ldsK = smem + cur * BUF;
         const char* ldsV = ldsK + NP * TILE;
@@ -212,32 +230,87 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
         // PRE (q pre-scaled by dh^-0.5*log2e in the projection epilogue): the accumulators START at the
         // gated bias, so the MFMA chain delivers finished exp2-domain scores (no per-score multiply/add).
         f32x16 st[2];
+        if constexpr (WIDE) {
+            f32x4 bvv[2][4];
+            bf16x8 kf[2][KS];
+            if (PRE && TBL) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            if (PRE && p.table) {
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
-                    const f32x4 bv = *(const f32x4*)(bcopy + kb);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = gq2 * bv[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        bvv[sub][g4] = *(const f32x4*)(bcopy + kt * ABKV + sub * 32 + 8 * g4 + 4 * hh);
             }
-            const int key = sub * 32 + l31;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int off = key * RS + (k_swz<DHP>(key, ks * 2 + hh) << 4);
-                const bf16x8 kh = *(const bf16x8*)(ldsK + off);
-                st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ks], st[sub], 0, 0, 0);
-                if (NP == 2) {
-                    const bf16x8 kl = *(const bf16x8*)(ldsK + TILE + off);
-                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ks], st[sub], 0, 0, 0);
-                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[NP - 1][ks], st[sub], 0, 0, 0);
+            for (int sub = 0; sub < 2; ++sub) {
+                const int key = sub * 32 + l31;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    kf[sub][ks] = *(const bf16x8*)(ldsK + key * RS + (k_swz<DHP>(key, ks * 2 + hh) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = (PRE && TBL) ? gq2 * bvv[sub][g4][r] : 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)                          // the two key halves are independent chains
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[0][ks], st[sub], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                if (PRE && TBL) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
+                        const f32x4 bv = *(const f32x4*)(bcopy + kb);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = gq2 * bv[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+                }
+                const int key = sub * 32 + l31;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int off = key * RS + (k_swz<DHP>(key, ks * 2 + hh) << 4);
+                    const bf16x8 kh = *(const bf16x8*)(ldsK + off);
+                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ks], st[sub], 0, 0, 0);
+                    if (NP == 2) {
+                        const bf16x8 kl = *(const bf16x8*)(ldsK + TILE + off);
+                        st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ks], st[sub], 0, 0, 0);
+                        st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[NP - 1][ks], st[sub], 0, 0, 0);
+                    }
                 }
             }
+        }
+
+        // transposed V reads: lane (qq,pp) of its 16-lane group addresses key kb+qq, 8 bytes at pp
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const int vg = lane >> 4, vqq = (lane >> 2) & 3, vpp = lane & 3;
+        auto v_frag = [&](const char* plane, int sub, int s2, int ds) -> bf16x8 {
+            const int kb = sub * 32 + s2 * 16 + 4 * (vg >> 1);
+            const int key0 = kb + vqq, key1 = kb + 8 + vqq;
+            const int o0 = key0 * RS + (v_unit_swz<DHP>(key0, ds) << 6) + ((vg & 1) << 5) + (vpp << 3);
+            const int o1 = key1 * RS + (v_unit_swz<DHP>(key1, ds) << 6) + ((vg & 1) << 5) + (vpp << 3);
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + o0));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(plane + o1));
+            const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        bf16x8 vfr[WIDE ? 2 : 1][WIDE ? 2 : 1][WIDE ? DSUB : 1];
+        if constexpr (WIDE) {                                        // requested now: they land under the QK MFMAs / the max
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int ds = 0; ds < DSUB; ++ds) vfr[sub][s2][ds] = v_frag(ldsV, sub, s2, ds);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- scores (log2 domain) and running max
@@ -248,7 +321,7 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (!PRE && p.table) bv = *(const f32x4*)(bcopy + kb);
+                if (!PRE && TBL) bv = *(const f32x4*)(bcopy + kb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = PRE ? st[sub][4 * g4 + r] : fmaf(st[sub][4 * g4 + r], c1, gq2 * bv[r]);
@@ -257,20 +330,12 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
                     mloc = fmaxf(mloc, v);
                 }
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        {   // other half-wave's maximum for the same query: one v_permlane32_swap instead of an LDS bpermute
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+            mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float lsum = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(st[sub][r] - m_new);
-                st[sub][r] = e;
-                lsum += e;
-            }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
         m_run = m_new;
         if (!__all(alpha == 1.0f)) {                                 // wave-uniform: most tiles after the first few skip it
 #pragma unroll
@@ -279,43 +344,40 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
                 for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
         }
 
-        // ---- O^T += V^T P^T : accumulator registers 8s..8s+7 are the B fragment of k-step s
+        // ---- P = exp2(S - m) and O^T += V^T P^T, 16 keys at a time: accumulator registers 8s..8s+7 of a key half
+        // are the B fragment of k-step s, so the exponentials of the next 16 keys issue while these MFMAs run
+        float lsum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 ph, plo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float e = st[sub][8 * s + j];
+                    const float e = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
+                    lsum += e;
                     const __bf16 hi = (__bf16)e;
                     ph[j] = hi;
                     if (NP == 2) plo[j] = (__bf16)(e - (float)hi);
                 }
-                // transposed V reads: lane (qq,pp) of its 16-lane group addresses key kb+qq, 8 bytes at pp
-                const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-                const int kb = sub * 32 + s * 16 + 4 * (g >> 1);
 #pragma unroll
                 for (int ds = 0; ds < DSUB; ++ds) {
-                    const int key0 = kb + qq, key1 = kb + 8 + qq;
-                    const int o0 = key0 * RS + (v_unit_swz<DHP>(key0, ds) << 6) + ((g & 1) << 5) + (pp << 3);
-                    const int o1 = key1 * RS + (v_unit_swz<DHP>(key1, ds) << 6) + ((g & 1) << 5) + (pp << 3);
-                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + o0));
-                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + o1));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                    const bf16x8 vh = __builtin_bit_cast(bf16x8, av);
+                    bf16x8 vh;
+                    if constexpr (WIDE) vh = vfr[sub][s2][ds];
+                    else vh = v_frag(ldsV, sub, s2, ds);
                     ot[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[ds], 0, 0, 0);
                     if (NP == 2) {
-                        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + TILE + o0));
-                        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + TILE + o1));
-                        const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                        const bf16x8 vl = __builtin_bit_cast(bf16x8, bv);
+                        const bf16x8 vl = v_frag(ldsV + TILE, sub, s2, ds);
                         ot[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[ds], 0, 0, 0);
                         ot[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, plo, ot[ds], 0, 0, 0);
                     }
                 }
             }
+        {   // the other half-wave summed the other 32 keys of this query
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+            lsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        l_run = l_run * alpha + lsum;
 
         // ---- publish the next tile
         if (kt + 1 < nkt) {
@@ -350,9 +412,9 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
     }
 }
 
-template <int DHP, int MODE, bool PRE>
+template <int DHP, int MODE, bool PRE, bool TBL>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE, PRE>;
+    auto k = attention_kernel<DHP, MODE, PRE, TBL>;
     static bool ready = false;
     if (lds > 65536 && !ready) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -402,7 +464,8 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * p.nq), 1, 1);
     hipStream_t s = (hipStream_t)stream;
     const bool pre = scale <= 0.f;
-#define SER_ATTN(D_, M_) (pre ? launch_attention<D_, M_, true>(p, grid, lds, s) : launch_attention<D_, M_, false>(p, grid, lds, s))
+#define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
+                              : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
     if (dhp == 64 && np == 1) return SER_ATTN(64, SER_MODE_BF16);
     if (dhp == 64) return SER_ATTN(64, SER_MODE_FP32X);
     if (np == 1) return SER_ATTN(128, SER_MODE_BF16);

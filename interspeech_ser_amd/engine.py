@@ -105,6 +105,9 @@ class _EncoderBase:
         # when a list, every ser_gemm launch appends (start_event, end_event, algorithmic_flops):
         # bench.py uses it for the live roofline figure of the dominant kernel
         self.gemm_trace: Optional[list] = None
+        # when a list, every encoder layer appends (start_event, end_event, utterances) around its attention block
+        # (packed QKV projection -> attention -> output projection): bench.py's "attention_block" figure
+        self.block_trace: Optional[list] = None
 
     # ------------------------------------------------------------------ weights
     def _dev_f32(self, t: torch.Tensor) -> torch.Tensor:
@@ -229,6 +232,9 @@ class _EncoderBase:
             x = states[i]
             last = i + 1 == L
             nxt = pl["last"] if last else states[i + 1]
+            if self.block_trace is not None:
+                b0 = torch.cuda.Event(enable_timing=True)
+                b0.record()
             # q columns leave the projection already multiplied by dh^-0.5 * log2(e)
             self._gemm(pl["xa"], lay["qkv"], M, ln_stats=(pl["px0"] if i == 0 else pl["px"]), ln_groups=gx,
                        out_act=pl["qkv"], col_scale=geo.head_dim ** -0.5 * 1.4426950408889634, col_scale_end=D)
@@ -239,6 +245,10 @@ class _EncoderBase:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
             self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D,
                        out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD)
+            if self.block_trace is not None:
+                b1 = torch.cuda.Event(enable_timing=True)
+                b1.record()
+                self.block_trace.append((b0, b1, B))
             self._gemm(pl["ha"], lay["fc1"], M, ln_stats=pl["ph"], ln_groups=gD, act=_lib.ACT_GELU, out_act=pl["ffn"])
             if last:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
