@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 6
+#define SER_ABI_VERSION 7
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -192,6 +192,15 @@ int ser_mean4(const float* s0, const float* s1, const float* s2, const float* s3
 
 /* weights: fp32 -> bf16 hi (+ lo) planes, done once at load. */
 int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, int64_t n, void* stream);
+
+/* Row-index tables of a packed ragged batch, built on the device (no per-batch host tables to upload):
+ *   out[m] = (base[b] + step * (m - row_offs[b])) * mult / div      for row_offs[b] <= m < row_offs[b+1]
+ * row_offs: [B+1] int32 first output row of every utterance; base: [B] int64.  This is the implicit-conv row offset
+ * table ser_gemm_args.a_rowoff of a strided Conv1d over packed utterances (base = first input row, step = stride,
+ * mult = C_in, div = 8), the positional conv's halo map, and every other "utterance b starts here" table that
+ * replaces the reference's padded [B, T] indexing (preprocess_speech.py:49 runs B = 1, so it never needs one). */
+int ser_ragged_index(const int32_t* row_offs, const int64_t* base, int B, int64_t step, int64_t mult, int64_t div,
+                     int32_t* out, int64_t total_rows, void* stream);
 
 #define SER_WS_LOGMEL 1
 #define SER_WS_WAVE_FRAMES 2

@@ -18,7 +18,7 @@ ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
 WS_WAVE_FRAMES = 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -65,6 +65,7 @@ _SIGNATURES = {
     "ser_pack_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "ser_mean4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ser_split_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p]),
+    "ser_ragged_index": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64, c_void_p]),
     "ser_workspace_bytes": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
 }
 

@@ -509,6 +509,30 @@ __global__ void split_kernel(const float* __restrict__ x, unsigned short* __rest
     }
 }
 
+// out[m] = (base[b] + step * (m - row_offs[b])) * mult / div with b = utterance owning output row m
+__global__ void ragged_index_kernel(const int32_t* __restrict__ row_offs, const int64_t* __restrict__ base, int B,
+                                    int64_t step, int64_t mult, int64_t div, int32_t* __restrict__ out, int64_t total) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= total) return;
+    int lo = 0, hi = B;                              // largest b with row_offs[b] <= m (empty utterances skipped)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)row_offs[mid] <= m) lo = mid; else hi = mid;
+    }
+    out[m] = (int32_t)((base[lo] + step * (m - (int64_t)row_offs[lo])) * mult / div);
+}
+
+extern "C" int ser_ragged_index(const int32_t* row_offs, const int64_t* base, int B, int64_t step, int64_t mult, int64_t div,
+                                int32_t* out, int64_t total_rows, void* stream) {
+    if (!row_offs || !base || !out) return ser_fail(-1, "ser_ragged_index: null pointer");
+    if (B <= 0 || total_rows < 0 || div <= 0) return ser_fail(-2, "ser_ragged_index: bad B=%d / rows / div", B);
+    if (total_rows == 0) return 0;
+    const int64_t blocks = (total_rows + 255) / 256;
+    hipLaunchKernelGGL(ragged_index_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, row_offs, base, B,
+                       step, mult, div, out, total_rows);
+    return ser_check_launch("ser_ragged_index");
+}
+
 extern "C" int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, int64_t n, void* stream) {
     if (!x || !out || n <= 0) return ser_fail(-1, "ser_split_bf16: bad arguments");
     int64_t blocks = (n + 255) / 256;

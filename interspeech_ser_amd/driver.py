@@ -122,7 +122,7 @@ class _Extractor:
         self.average = args.use_average == "y"
 
     def extract(self, waves: List[np.ndarray], layer_index: int) -> List[torch.Tensor]:
-        """One ragged batch -> one CPU [T, D] tensor per utterance (rows a19/a20)."""
+        """One ragged batch -> one CPU [T, D] tensor per utterance (rows a19/a20), synchronously."""
         from .engine import mean_last4
         lengths = [len(w) for w in waves]
         hs = self.enc.forward(self.enc.upload(waves), lengths)
@@ -135,6 +135,49 @@ class _Extractor:
                 rows = rows[: whisper_saved_rows(n, rows.shape[1])]
             out.append(rows)
         return out
+
+    # ---- pipelined form: two slots (arena + HIP stream each), so batch i+1 is uploaded and launched while batch i
+    # still computes, and its D2H copy / slicing / torch.save overlap the next forward
+    SLOTS = 2
+
+    def submit(self, waves: List[np.ndarray], layer_index: int, slot: int):
+        """Enqueue upload -> forward -> selection -> D2H of one ragged batch on slot ``slot``'s stream; returns a
+        ticket for ``collect``.  Nothing here waits for the GPU."""
+        from .engine import mean_last4
+        if self.whisper:
+            raise RuntimeError("the pipelined path serves the wav2vec2-style encoders")
+        st = self.__dict__.setdefault("_streams", {})
+        if slot not in st:
+            st[slot] = torch.cuda.Stream(device=self.enc.device)
+        lengths = [len(w) for w in waves]
+        with torch.cuda.stream(st[slot]):
+            hs = self.enc.forward(self.enc.upload(waves, slot), lengths, slot=slot)
+            sel = mean_last4(hs) if self.average else hs.states[layer_index]
+            host = self._pinned_out(slot, sel.shape[0], sel.shape[1])
+            host.copy_(sel, non_blocking=True)
+            evt = torch.cuda.Event()
+            evt.record()
+        return dict(slot=slot, event=evt, host=host, frame_offs=list(hs.frame_offs), lengths=lengths)
+
+    def collect(self, ticket) -> List[torch.Tensor]:
+        """Wait for a ticket's D2H copy; one [T, D] view of the slot's pinned buffer per utterance (valid until
+        the slot's next ``submit``; ``hold`` defers that until the given futures are done)."""
+        ticket["event"].synchronize()
+        host, fo = ticket["host"], ticket["frame_offs"]
+        return [host[fo[b]: fo[b + 1]] for b in range(len(ticket["lengths"]))]
+
+    def hold(self, slot: int, futures) -> None:
+        self.__dict__.setdefault("_held", {})[slot] = list(futures)
+
+    def _pinned_out(self, slot: int, rows: int, cols: int) -> torch.Tensor:
+        for f in self.__dict__.setdefault("_held", {}).pop(slot, []):
+            f.result()                                        # writers still reading the buffer we are about to refill
+        pool = self.__dict__.setdefault("_pin_out", {})
+        buf = pool.get(slot)
+        if buf is None or buf.shape[1] != cols or buf.shape[0] < rows:
+            buf = torch.empty((max(rows, 1024), cols), dtype=torch.float32).pin_memory()
+            pool[slot] = buf
+        return buf[:rows]
 
 
 def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
@@ -215,9 +258,40 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
     done = 0
     audio_s = 0.0
     bar = tqdm(total=len(mine), desc="Extracting features", disable=(rank != 0))
+    from collections import deque
+    pipelined = not whisper
     with ThreadPoolExecutor(max_workers=max(1, args.num_workers)) as pool:
         pending = pool.map(decode, batches[0]) if batches else []
         writes = []
+        inflight = deque()
+
+        def one_by_one(good):
+            """A failed batch is retried per utterance so one bad file cannot drop its neighbours."""
+            nonlocal done, audio_s
+            torch.cuda.synchronize()                          # the synchronous path shares slot 0's arena with the pipeline
+            for path, wave in good:
+                try:
+                    f = ex.extract([wave], layer_index)[0]
+                    writes.append(pool.submit(write, (path, f)))
+                    done += 1
+                    audio_s += len(wave) / 16000.0
+                except Exception as e1:                       # noqa: BLE001
+                    print(f"Failed to process {path}: {e1}")
+
+        def finish(ticket):
+            nonlocal done, audio_s
+            good = ticket["good"]
+            try:
+                feats = ex.collect(ticket)
+            except Exception:                                 # noqa: BLE001
+                one_by_one(good)
+                return
+            futs = [pool.submit(write, (path, f)) for (path, _), f in zip(good, feats)]
+            ex.hold(ticket["slot"], futs)
+            writes.extend(futs)
+            done += len(good)
+            audio_s += sum(len(w) for _, w in good) / 16000.0
+
         for bi, batch in enumerate(batches):
             decoded = list(pending)
             if bi + 1 < len(batches):
@@ -232,22 +306,25 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
                 try:
                     if layer_index is not None and not 0 <= layer_index < num_states:
                         raise IndexError("tuple index out of range")
-                    feats = ex.extract([w for _, w in good], layer_index)
-                    for (path, wave), f in zip(good, feats):
-                        writes.append(pool.submit(write, (path, f)))
-                        audio_s += len(wave) / 16000.0
-                    done += len(good)
-                except Exception as e:                    # noqa: BLE001
-                    # a failed batch is retried per utterance so one bad file cannot drop its neighbours
-                    for path, wave in good:
-                        try:
-                            f = ex.extract([wave], layer_index)[0]
+                    if pipelined:
+                        ticket = ex.submit([w for _, w in good], layer_index, slot=bi % ex.SLOTS)
+                        ticket["good"] = good
+                        inflight.append(ticket)
+                    else:
+                        feats = ex.extract([w for _, w in good], layer_index)
+                        for (path, wave), f in zip(good, feats):
                             writes.append(pool.submit(write, (path, f)))
-                            done += 1
                             audio_s += len(wave) / 16000.0
-                        except Exception as e1:           # noqa: BLE001
-                            print(f"Failed to process {path}: {e1}")
+                        done += len(good)
+                except Exception:                             # noqa: BLE001
+                    while inflight:                           # keep the per-slot order simple: drain, then retry singly
+                        finish(inflight.popleft())
+                    one_by_one(good)
+            while len(inflight) > 1:                          # one batch stays in flight while the next is prepared
+                finish(inflight.popleft())
             bar.update(len(batch))
+        while inflight:
+            finish(inflight.popleft())
         for w in writes:
             w.result()
     bar.close()

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_binding_covers_header(built_library):
     from interspeech_ser_amd import _lib
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
-    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 7
 
 
 def test_gemm_args_layout_matches_c(built_library, tmp_path):

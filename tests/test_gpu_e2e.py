@@ -242,3 +242,36 @@ def test_full_size_wavlm_large_pins(golden_dir):
         assert abs(float(st.norm()) - float(gold["l2"][layer])) / float(gold["l2"][layer]) < 1e-3
     print(f"wavlm-large fp32x probes: worst rel err {worst:.3e}")
     assert worst < 1e-3, worst
+
+
+def test_pipelined_slots_equal_synchronous_path():
+    """Ragged batches through the two-slot pipeline (arena re-use, device-built row tables, two HIP streams, pinned
+    D2H) give bit-identical features to the synchronous one-batch-at-a-time path."""
+    import types
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.driver import _Extractor
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_WAVLM
+    sd = synthetic_state_dict(geo, 3)
+    ex = _Extractor.__new__(_Extractor)
+    ex.whisper, ex.average, ex.geo = False, False, geo
+    ex.enc = SpeechEncoder(geo, sd, "cuda:0", mode="fp32x")
+    rng = np.random.default_rng(5)
+    batches = []
+    for k in range(6):                                            # growing, shrinking and repeated shapes
+        lens = [int(n) for n in rng.integers(400, 30000, size=int(rng.integers(1, 6)))]
+        batches.append([synth_wave(100 * k + i, n) for i, n in enumerate(lens)])
+    batches.append(batches[2])
+    want = [[t.clone() for t in ex.extract(b, 2)] for b in batches]
+    torch.cuda.synchronize()
+    got, inflight = [], []
+    for k, b in enumerate(batches):
+        inflight.append(ex.submit(b, 2, slot=k % 2))
+        if len(inflight) > 1:
+            got.append([t.clone() for t in ex.collect(inflight.pop(0))])
+    got.append([t.clone() for t in ex.collect(inflight.pop(0))])
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert len(g) == len(w)
+        for a, b in zip(g, w):
+            assert a.shape == b.shape and torch.equal(a, b), k

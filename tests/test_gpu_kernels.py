@@ -668,3 +668,20 @@ def test_logmel_whisper(L, golden_dir):
     for b, w in enumerate(waves):
         ref = O.whisper_log_mel(w, 128)
         assert np.abs(got[b] - ref).max() < 1e-3, np.abs(got[b] - ref).max()
+
+
+@pytest.mark.parametrize("step,mult,div", [(2, 512, 8), (1, 1, 1), (1, 1024, 8), (5, 64, 8)])
+def test_ragged_index_tables_match_numpy(L, step, mult, div):
+    """ser_ragged_index == the host-side table it replaces (implicit-conv row offsets, halo map)."""
+    rng = np.random.default_rng(step * 7 + mult)
+    counts = rng.integers(1, 700, size=37)
+    counts[5] = 1
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    base = (rng.integers(0, 100000, size=37)).astype(np.int64)
+    want = np.concatenate([(base[b] + step * np.arange(counts[b], dtype=np.int64)) * mult // div for b in range(37)]).astype(np.int32)
+    d_offs, d_base = torch.from_numpy(offs).to(DEV), torch.from_numpy(base).to(DEV)
+    out = torch.full((int(offs[-1]) + 3,), -7, dtype=torch.int32, device=DEV)
+    L.check(L.lib.ser_ragged_index(d_offs.data_ptr(), d_base.data_ptr(), 37, step, mult, div, out.data_ptr(), int(offs[-1]),
+                                   torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:-3], want) and (got[-3:] == -7).all()
