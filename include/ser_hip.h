@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 7
+#define SER_ABI_VERSION 8
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -201,6 +201,50 @@ int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, in
  * replaces the reference's padded [B, T] indexing (preprocess_speech.py:49 runs B = 1, so it never needs one). */
 int ser_ragged_index(const int32_t* row_offs, const int64_t* base, int B, int64_t step, int64_t mult, int64_t div,
                      int32_t* out, int64_t total_rows, void* stream);
+
+/* ---- command lists -----------------------------------------------------------------------------------------------
+ * A forward over a packed ragged batch is ~150 launches whose POINTERS are fixed once the host has laid its buffers out
+ * and whose only per-batch variables are a handful of row counts.  The host therefore records the launches once as an
+ * array of ser_cmd, patches the row counts in place for every batch and replays the array with ONE call: the launching
+ * thread leaves the interpreter once per batch instead of once per kernel (the reference pays one Python dispatch per
+ * torch op, preprocess_speech.py:49).  Each ser_cmd carries the arguments of the launcher of the same name. */
+typedef struct ser_attention_args {
+    const void* qkv; int64_t ld; int64_t plane_stride; int32_t q_col, k_col, v_col, B;
+    const int32_t* frame_offs; const float* table; const float* gate;
+    int32_t max_frames, table_T;
+    void* out; int64_t ldo; int64_t out_plane_stride;
+    int32_t H, dh; float scale; int32_t mode; int32_t gate_col, reserved0;
+    const float* gru_const; const int32_t* key_lens;
+} ser_attention_args;
+
+typedef struct ser_layernorm_args {
+    const float* x; int64_t ldx; const float* g; const float* b; float eps; int32_t gelu;
+    float* out_f32; int64_t ldo_f32; void* out_act; int64_t ldo_act; int64_t out_plane_stride;
+    int32_t mode, rows, D, reserved0;
+} ser_layernorm_args;
+
+typedef struct ser_wave_frames_args {
+    const float* wav; const int64_t* sample_offs; const int32_t* frame_offs; int32_t B, k, stride, mode;
+    void* out; int64_t out_plane_stride; void* work; int32_t total_rows, reserved0;
+} ser_wave_frames_args;
+
+#define SER_OP_GEMM 1
+#define SER_OP_ATTENTION 2
+#define SER_OP_LAYERNORM 3
+#define SER_OP_WAVE_FRAMES 4
+typedef struct ser_cmd {
+    int32_t op, reserved0;
+    union {
+        ser_gemm_args        gemm;
+        ser_attention_args   attention;
+        ser_layernorm_args   layernorm;
+        ser_wave_frames_args wave_frames;
+    } u;
+} ser_cmd;
+
+/* Enqueue cmds[0..n) in order on `stream`.  Stops at the first launcher that fails and returns its code
+ * (ser_last_error() names it); *failed_at, if not NULL, receives the index. */
+int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void* stream);
 
 #define SER_WS_LOGMEL 1
 #define SER_WS_WAVE_FRAMES 2

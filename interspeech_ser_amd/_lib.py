@@ -18,7 +18,7 @@ ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
 WS_WAVE_FRAMES = 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -43,6 +43,52 @@ class GemmArgs(C.Structure):
     ]
 
 
+class AttentionArgs(C.Structure):
+    """Mirror of ``ser_attention_args``."""
+    _fields_ = [
+        ("qkv", c_void_p), ("ld", c_i64), ("plane_stride", c_i64),
+        ("q_col", C.c_int32), ("k_col", C.c_int32), ("v_col", C.c_int32), ("B", C.c_int32),
+        ("frame_offs", c_void_p), ("table", c_void_p), ("gate", c_void_p),
+        ("max_frames", C.c_int32), ("table_T", C.c_int32),
+        ("out", c_void_p), ("ldo", c_i64), ("out_plane_stride", c_i64),
+        ("H", C.c_int32), ("dh", C.c_int32), ("scale", c_float), ("mode", C.c_int32),
+        ("gate_col", C.c_int32), ("reserved0", C.c_int32),
+        ("gru_const", c_void_p), ("key_lens", c_void_p),
+    ]
+
+
+class LayerNormArgs(C.Structure):
+    """Mirror of ``ser_layernorm_args``."""
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_i64), ("g", c_void_p), ("b", c_void_p), ("eps", c_float), ("gelu", C.c_int32),
+        ("out_f32", c_void_p), ("ldo_f32", c_i64), ("out_act", c_void_p), ("ldo_act", c_i64), ("out_plane_stride", c_i64),
+        ("mode", C.c_int32), ("rows", C.c_int32), ("D", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+class WaveFramesArgs(C.Structure):
+    """Mirror of ``ser_wave_frames_args``."""
+    _fields_ = [
+        ("wav", c_void_p), ("sample_offs", c_void_p), ("frame_offs", c_void_p),
+        ("B", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("mode", C.c_int32),
+        ("out", c_void_p), ("out_plane_stride", c_i64), ("work", c_void_p),
+        ("total_rows", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+class _CmdUnion(C.Union):
+    _fields_ = [("gemm", GemmArgs), ("attention", AttentionArgs), ("layernorm", LayerNormArgs), ("wave_frames", WaveFramesArgs)]
+
+
+class Cmd(C.Structure):
+    """Mirror of ``ser_cmd``: one recorded launch of a command list (``ser_run``)."""
+    _fields_ = [("op", C.c_int32), ("reserved0", C.c_int32), ("u", _CmdUnion)]
+
+
+OP_GEMM, OP_ATTENTION, OP_LAYERNORM, OP_WAVE_FRAMES = 1, 2, 3, 4
+STRUCT_MIRRORS = {"ser_gemm_args": GemmArgs, "ser_attention_args": AttentionArgs, "ser_layernorm_args": LayerNormArgs,
+                  "ser_wave_frames_args": WaveFramesArgs, "ser_cmd": Cmd}
+
 _SIGNATURES = {
     "ser_version": (c_int, []),
     "ser_last_error": (C.c_char_p, []),
@@ -65,6 +111,7 @@ _SIGNATURES = {
     "ser_pack_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "ser_mean4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ser_split_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p]),
+    "ser_run": (c_int, [c_void_p, C.c_int32, c_void_p, c_void_p]),
     "ser_ragged_index": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64, c_void_p]),
     "ser_workspace_bytes": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
 }

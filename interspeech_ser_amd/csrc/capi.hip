@@ -37,3 +37,44 @@ extern "C" size_t ser_workspace_bytes(int op, int B, int T, int D, int H, int mo
             return 0;
     }
 }
+
+
+// ---- command lists (see ser_hip.h): one foreign call per batch instead of one per kernel ------------------------
+extern "C" int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void* stream) {
+    if (!cmds || n < 0) return ser_fail(-1, "ser_run: bad command list");
+    for (int32_t i = 0; i < n; ++i) {
+        const ser_cmd& c = cmds[i];
+        int rc;
+        switch (c.op) {
+            case SER_OP_GEMM:
+                rc = ser_gemm(&c.u.gemm, stream);
+                break;
+            case SER_OP_ATTENTION: {
+                const ser_attention_args& a = c.u.attention;
+                rc = ser_attention(a.qkv, a.ld, a.plane_stride, a.q_col, a.k_col, a.v_col, a.frame_offs, a.B, a.max_frames,
+                                   a.table, a.table_T, a.gate, a.out, a.ldo, a.out_plane_stride, a.H, a.dh, a.scale, a.mode,
+                                   a.gate_col, a.gru_const, a.key_lens, stream);
+                break;
+            }
+            case SER_OP_LAYERNORM: {
+                const ser_layernorm_args& a = c.u.layernorm;
+                rc = ser_layernorm(a.x, a.ldx, a.g, a.b, a.eps, a.gelu, a.out_f32, a.ldo_f32, a.out_act, a.ldo_act,
+                                   a.out_plane_stride, a.mode, a.rows, a.D, stream);
+                break;
+            }
+            case SER_OP_WAVE_FRAMES: {
+                const ser_wave_frames_args& a = c.u.wave_frames;
+                rc = ser_wave_frames(a.wav, a.sample_offs, a.frame_offs, a.B, a.k, a.stride, a.out, a.out_plane_stride, a.mode,
+                                     a.work, a.total_rows, stream);
+                break;
+            }
+            default:
+                rc = ser_fail(-2, "ser_run: command %d has unknown op %d", i, c.op);
+        }
+        if (rc != 0) {
+            if (failed_at) *failed_at = i;
+            return rc;
+        }
+    }
+    return 0;
+}

@@ -55,6 +55,7 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
                    help="local *.safetensors / pytorch_model.bin (or directory); default: HF cache lookup, "
                         "else seeded synthetic weights")
     p.add_argument("--skip_existing", action="store_true")
+    p.add_argument("--timing", action="store_true", help="print where the launching thread spent its time")
     p.add_argument("--compat_layer_quirk", action="store_true",
                    help="speech driver: index hidden_states with the number of files found in --save_path at "
                         "start-up, like the reference does")
@@ -150,13 +151,23 @@ class _Extractor:
         if slot not in st:
             st[slot] = torch.cuda.Stream(device=self.enc.device)
         lengths = [len(w) for w in waves]
+        tm = self.__dict__.setdefault("tm", dict(upload=0.0, forward=0.0, d2h=0.0))
+        clock = time.perf_counter
         with torch.cuda.stream(st[slot]):
-            hs = self.enc.forward(self.enc.upload(waves, slot), lengths, slot=slot)
+            t0 = clock()
+            dev = self.enc.upload(waves, slot)
+            t1 = clock()
+            hs = self.enc.forward(dev, lengths, slot=slot)
+            t2 = clock()
             sel = mean_last4(hs) if self.average else hs.states[layer_index]
             host = self._pinned_out(slot, sel.shape[0], sel.shape[1])
             host.copy_(sel, non_blocking=True)
             evt = torch.cuda.Event()
             evt.record()
+            t3 = clock()
+        tm["upload"] += t1 - t0
+        tm["forward"] += t2 - t1
+        tm["d2h"] += t3 - t2
         return dict(slot=slot, event=evt, host=host, frame_offs=list(hs.frame_offs), lengths=lengths)
 
     def collect(self, ticket) -> List[torch.Tensor]:
@@ -292,8 +303,12 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
             done += len(good)
             audio_s += sum(len(w) for _, w in good) / 16000.0
 
+        tm = dict(decode_wait=0.0, submit=0.0, finish=0.0)   # where the launching thread spends its time (--timing)
+        clock = time.perf_counter
         for bi, batch in enumerate(batches):
+            t_a = clock()
             decoded = list(pending)
+            tm["decode_wait"] += clock() - t_a
             if bi + 1 < len(batches):
                 pending = pool.map(decode, batches[bi + 1])          # decode the next batch while the GPU works
             good = []
@@ -307,7 +322,9 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
                     if layer_index is not None and not 0 <= layer_index < num_states:
                         raise IndexError("tuple index out of range")
                     if pipelined:
+                        t_a = clock()
                         ticket = ex.submit([w for _, w in good], layer_index, slot=bi % ex.SLOTS)
+                        tm["submit"] += clock() - t_a
                         ticket["good"] = good
                         inflight.append(ticket)
                     else:
@@ -320,8 +337,10 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
                     while inflight:                           # keep the per-slot order simple: drain, then retry singly
                         finish(inflight.popleft())
                     one_by_one(good)
+            t_a = clock()
             while len(inflight) > 1:                          # one batch stays in flight while the next is prepared
                 finish(inflight.popleft())
+            tm["finish"] += clock() - t_a
             bar.update(len(batch))
         while inflight:
             finish(inflight.popleft())
@@ -331,6 +350,10 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
     dt = time.perf_counter() - t0
     total_done, wall = D.sum_over_ranks(done), D.max_over_ranks(dt)
     log(f"{int(total_done)} utterances on {world} GPU(s) in {wall:.2f} s ({total_done / max(wall, 1e-9):.1f} utt/s)")
+    if args.timing:
+        log("launch thread: " + ", ".join(f"{k} {v:.3f} s" for k, v in tm.items()) + f", total {dt:.3f} s")
+        if getattr(ex, "tm", None):
+            log("  submit = " + ", ".join(f"{k} {v:.3f} s" for k, v in ex.tm.items()))
     D.shutdown()
     return 0
 

@@ -40,6 +40,63 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class Sz(int):
+    """A per-batch size (row count, utterances, longest utterance) that remembers its name.  It is an ``int`` everywhere;
+    a launch recorded into a command list keeps the name so the field can be patched for the next batch."""
+
+    def __new__(cls, value: int, name: str):
+        o = int.__new__(cls, value)
+        o.name = name
+        return o
+
+
+class Tape:
+    """The launches of one forward over a slot's arena, recorded as ``ser_cmd`` entries (include/ser_hip.h).  Pointers
+    in an arena never change, so a later batch only patches its sizes (``Sz`` fields) and replays everything with one
+    ``ser_run`` call: ~150 Python -> C transitions per batch become one."""
+
+    def __init__(self, capacity: int = 640):
+        self.cmds = (_lib.Cmd * capacity)()
+        self.n = 0
+        self.patches = []                    # (struct view inside cmds, field name, size name)
+        self.inputs: Dict[str, tuple] = {}   # named per-batch pointers, e.g. the uploaded waveform
+        self._failed = C.c_int32(-1)
+
+    def slot(self, union_field: str):
+        if self.n >= len(self.cmds):
+            raise _lib.SerHipError("command list capacity exceeded")
+        return getattr(self.cmds[self.n].u, union_field)
+
+    def commit(self, op: int, view, **sizes) -> None:
+        self.cmds[self.n].op = op
+        for field, value in sizes.items():
+            if isinstance(value, Sz):
+                self.patches.append((view, field, value.name))
+        self.n += 1
+
+    def run(self, sizes: Dict[str, int], stream: int) -> None:
+        for view, field, name in self.patches:
+            setattr(view, field, sizes[name])
+        rc = lib.ser_run(self.cmds, self.n, C.byref(self._failed), stream)
+        if rc != 0:
+            check(rc, f"ser_run (command {self._failed.value} of {self.n})")
+
+
+def _on_stream(fn):
+    """Look the launch stream up once for the whole forward (see ``_EncoderBase._s``)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        prev = self._st
+        self._st = _stream()
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self._st = prev
+    return wrapped
+
+
 class Act:
     """bf16 GEMM operand with 1 (bf16) or 2 (hi/lo) planes: tensor [planes, rows, cols]."""
 
@@ -108,6 +165,12 @@ class _EncoderBase:
         # when a list, every encoder layer appends (start_event, end_event, utterances) around its attention block
         # (packed QKV projection -> attention -> output projection): bench.py's "attention_block" figure
         self.block_trace: Optional[list] = None
+        self._st: Optional[int] = None      # launch stream of the forward in progress (looked up once per forward)
+        self._rec: Optional[Tape] = None    # when set, the launch helpers record into it instead of launching
+
+    def _s(self) -> int:
+        """HIP stream of the current forward: torch.cuda.current_stream() costs ~15 us and a forward makes ~150 launches."""
+        return self._st if self._st is not None else _stream()
 
     # ------------------------------------------------------------------ weights
     def _dev_f32(self, t: torch.Tensor) -> torch.Tensor:
@@ -146,7 +209,8 @@ class _EncoderBase:
               out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0,
               ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0,
               col_scale=1.0, col_scale_end=0):
-        g = GemmArgs()
+        rec = self._rec
+        g = rec.slot("gemm") if rec is not None else GemmArgs()
         g.A = a.ptr + a_ptr_offset
         g.a_plane_stride = a.plane_stride
         g.a_rowoff = _ptr(a_rowoff)
@@ -179,12 +243,15 @@ class _EncoderBase:
             g.stat_out, g.stat_groups = stat_out.data_ptr(), stat_groups
         g.f32_col_begin = f32_col_begin
         g.col_scale, g.col_scale_end = float(col_scale), int(col_scale_end)
+        if rec is not None:
+            rec.commit(_lib.OP_GEMM, g, M=M)
+            return
         if self.gemm_trace is None:
-            check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
+            check(lib.ser_gemm(C.byref(g), self._s()), "ser_gemm")
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.ser_gemm(C.byref(g), _stream()), "ser_gemm")
+        check(lib.ser_gemm(C.byref(g), self._s()), "ser_gemm")
         e1.record()
         # algorithmic FLOPs: 2*M*N*K over real (unpadded) channels, no tile-padding FLOPs
         k_real = g.K if k_algo is None else k_algo
@@ -197,20 +264,40 @@ class _EncoderBase:
     def _layernorm(self, x: torch.Tensor, ldx: int, ln, rows: int, D: int, *, gelu=False, out_f32=None,
                    out_act: Optional[Act] = None, eps=None):
         g, b = ln
-        check(lib.ser_layernorm(x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(),
-                                float(self.geo.layer_norm_eps if eps is None else eps), int(gelu),
-                                _ptr(out_f32), D if out_f32 is not None else 0,
-                                None if out_act is None else out_act.ptr,
-                                0 if out_act is None else out_act.cols,
-                                0 if out_act is None else out_act.plane_stride,
-                                self.mode, rows, D, _stream()), "ser_layernorm")
+        eps = float(self.geo.layer_norm_eps if eps is None else eps)
+        o_act = None if out_act is None else out_act.ptr
+        ldo_act = 0 if out_act is None else out_act.cols
+        ops = 0 if out_act is None else out_act.plane_stride
+        ldo_f32 = D if out_f32 is not None else 0
+        rec = self._rec
+        if rec is not None:
+            a = rec.slot("layernorm")
+            a.x, a.ldx, a.g, a.b, a.eps, a.gelu = x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu)
+            a.out_f32, a.ldo_f32, a.out_act, a.ldo_act, a.out_plane_stride = _ptr(out_f32), ldo_f32, o_act, ldo_act, ops
+            a.mode, a.rows, a.D = self.mode, rows, D
+            rec.commit(_lib.OP_LAYERNORM, a, rows=rows)
+            return
+        check(lib.ser_layernorm(x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu), _ptr(out_f32), ldo_f32,
+                                o_act, ldo_act, ops, self.mode, rows, D, self._s()), "ser_layernorm")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
                    gru_const=None, key_lens=None):
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
+        rec = self._rec
+        if rec is not None:
+            a = rec.slot("attention")
+            a.qkv, a.ld, a.plane_stride = qkv.ptr, qkv.cols, qkv.plane_stride
+            a.q_col, a.k_col, a.v_col, a.B = 0, D, 2 * D, B
+            a.frame_offs, a.table, a.gate = frame_offs_dev.data_ptr(), _ptr(table), _ptr(gate)
+            a.max_frames, a.table_T = max_frames, table_T
+            a.out, a.ldo, a.out_plane_stride = out.ptr, out.cols, out.plane_stride
+            a.H, a.dh, a.scale, a.mode, a.gate_col = H, dh, -1.0, self.mode, 3 * D        # q is pre-scaled
+            a.gru_const, a.key_lens = _ptr(gru_const), _ptr(key_lens)
+            rec.commit(_lib.OP_ATTENTION, a, B=B, max_frames=max_frames, table_T=table_T)
+            return
         check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
                                 max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
-                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _ptr(key_lens), _stream()),   # q is pre-scaled
+                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _ptr(key_lens), self._s()),   # q is pre-scaled
               "ser_attention")
 
     @staticmethod
@@ -449,7 +536,10 @@ class SpeechEncoder(_EncoderBase):
         if geo.family == FAMILY_WAVLM:
             ar["table"] = torch.empty(geo.heads * (2 * cap["Tmax"] - 1), dtype=torch.float32, device=dev)
         # small per-batch tables: one pinned host blob -> one async H2D into one device blob (int64 words)
-        words = 2 * (cap["B"] + 1) + (nl + 2) * (cap["B"] + 1) + (nl + 1) * cap["B"] + 64
+        # fixed regions of cap B + 2 words each (pointers into the blob must not move from batch to batch):
+        # sample_offs | offs[0..nl) (int32, two per word) | conv bases [1..nl) | halo base | pos base
+        ar["tab_region"] = cap["B"] + 2
+        words = (1 + nl + (nl - 1) + 2) * ar["tab_region"]
         ar["tab_host"] = torch.empty(words, dtype=torch.int64).pin_memory()
         ar["tab_dev"] = torch.empty(words, dtype=torch.int64, device=dev)
         ar["tab_evt"] = None
@@ -487,27 +577,27 @@ class SpeechEncoder(_EncoderBase):
         host32 = host64.view(np.int32)
         dev64 = ar["tab_dev"]
         dev32 = dev64.view(torch.int32)
-        w = 0                                               # cursor in int64 words
+        region = [0]                                        # next fixed region (int64 words)
 
         def put64(a):
-            nonlocal w
             a = np.asarray(a, dtype=np.int64)
+            w = region[0] * ar["tab_region"]
+            region[0] += 1
             host64[w:w + len(a)] = a
-            v = dev64[w:w + len(a)]
-            w += len(a)
-            return v
+            return dev64[w:w + len(a)]
 
         def put32(a):
-            nonlocal w
             a = np.asarray(a, dtype=np.int32)
+            w = region[0] * ar["tab_region"]
+            region[0] += 1
             host32[2 * w:2 * w + len(a)] = a
-            v = dev32[2 * w:2 * w + len(a)]
-            w += (len(a) + 1) // 2
-            return v
+            return dev32[2 * w:2 * w + len(a)]
 
         pl = dict(ar)                                       # arena buffers + this batch's views / numbers
-        pl.update(B=B, lengths=lengths, T=T, M=M, Tmax=Tmax, halo_rows=halo_rows)
-        pl["rows"] = [int(o[-1]) for o in offs]
+        pl["rows"] = [Sz(int(o[-1]), f"rows{i}") for i, o in enumerate(offs)]
+        pl["sizes"] = {f"rows{i}": int(r) for i, r in enumerate(pl["rows"])}
+        pl["sizes"].update(M=M, B=B, Tmax=Tmax)
+        pl.update(B=Sz(B, "B"), lengths=lengths, T=T, M=Sz(M, "M"), Tmax=Sz(Tmax, "Tmax"), halo_rows=halo_rows)
         pl["sample_offs"] = put64(np.concatenate([[0], np.cumsum(lengths)]))
         offs_dev = [put32(o) for o in offs]                 # offs[i][b] = first row of utterance b after conv layer i
         pl["frame_offs0"] = offs_dev[0]
@@ -516,7 +606,7 @@ class SpeechEncoder(_EncoderBase):
         starts = np.array([half * (b + 1) + offs[-1][b] for b in range(B)], dtype=np.int64)
         base_conv = [put64(offs[i - 1][:B]) for i in range(1, nl)]
         base_halo, base_pos = put64(starts), put64(starts - half)
-        dev64[:w].copy_(ar["tab_host"][:w], non_blocking=True)
+        dev64.copy_(ar["tab_host"], non_blocking=True)
         ar["tab_evt"] = torch.cuda.Event()
         ar["tab_evt"].record()
         # ---- O(rows) tables on the device
@@ -576,18 +666,46 @@ class SpeechEncoder(_EncoderBase):
         torch.cuda.current_stream().synchronize()
         return host
 
+    use_tape = True          # replay recorded command lists (one foreign call per forward); False = launch one by one
+
+    @_on_stream
     def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
         """packed raw samples [sum(lengths)] fp32 on the device -> L+1 hidden states."""
-        geo = self.geo
         pl = self._plan(lengths, slot)
+        if not self.use_tape or self.gemm_trace is not None or self.block_trace is not None:
+            self._launches(pl, packed_wave)                  # eager: one Python -> C transition per kernel
+        else:
+            ar = self._arenas[slot]
+            tape = ar.get("tape")
+            if tape is None:                                 # first forward in this arena: record, launch nothing
+                self._rec = tape = Tape()
+                try:
+                    self._launches(pl, packed_wave)
+                finally:
+                    self._rec = None
+                ar["tape"] = tape
+            tape.inputs["wav"].wav = packed_wave.data_ptr()
+            tape.run(pl["sizes"], self._s())
+        return HiddenStates(pl["states"], pl["frame_offs_host"])
+
+    def _launches(self, pl, packed_wave: torch.Tensor) -> None:
+        geo = self.geo
         B, M, D, C0 = pl["B"], pl["M"], geo.hidden, geo.conv_dim[0]
-        st = _stream()
         # a6 + a7 (layer 0): zero-mean / unit-variance per utterance fused with framing, then
         # Conv1d(1,C,10,5)+LayerNorm+GELU on the matrix cores (K padded to 64, LayerNorm epilogue)
         fr = pl["frames"]
-        check(lib.ser_wave_frames(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr(), B,
-                                  geo.conv_kernel[0], geo.conv_stride[0], fr.ptr, fr.plane_stride, self.mode,
-                                  pl["wave_work"].data_ptr(), pl["rows"][0], st), "ser_wave_frames")
+        rec = self._rec
+        if rec is not None:
+            a = rec.slot("wave_frames")
+            a.wav, a.sample_offs, a.frame_offs = packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr()
+            a.B, a.k, a.stride, a.mode = B, geo.conv_kernel[0], geo.conv_stride[0], self.mode
+            a.out, a.out_plane_stride, a.work, a.total_rows = fr.ptr, fr.plane_stride, pl["wave_work"].data_ptr(), pl["rows"][0]
+            rec.inputs["wav"] = a
+            rec.commit(_lib.OP_WAVE_FRAMES, a, B=B, total_rows=pl["rows"][0])
+        else:
+            check(lib.ser_wave_frames(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr(), B,
+                                      geo.conv_kernel[0], geo.conv_stride[0], fr.ptr, fr.plane_stride, self.mode,
+                                      pl["wave_work"].data_ptr(), pl["rows"][0], self._s()), "ser_wave_frames")
         a_in = pl["conv_act"][0]
         self._gemm(fr, self.conv0, pl["rows"][0], act=_lib.ACT_GELU, ln=self.conv_ln[0], ln_eps=1e-5, out_act=a_in,
                    k_algo=geo.conv_kernel[0])
@@ -621,7 +739,6 @@ class SpeechEncoder(_EncoderBase):
                    out_act=pl["xa"], stat_out=pl["px0"], stat_groups=pl["first_groups"])
         # a11/a12: stable-LayerNorm encoder layers (LayerNorms deferred into the GEMMs)
         self._run_layers(pl, states, pl["first_groups"], B, pl["Tmax"])
-        return HiddenStates(states, pl["frame_offs_host"])
 
 
 class WhisperEncoder(_EncoderBase):
@@ -701,6 +818,7 @@ class WhisperEncoder(_EncoderBase):
     def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int]) -> HiddenStates:
         return self.forward_features(self.log_mel(packed_wave, lengths), lengths)
 
+    @_on_stream
     def forward_features(self, input_features: torch.Tensor, lengths: Sequence[int]) -> HiddenStates:
         """a17: ``model.encoder(input_features, output_hidden_states=True).hidden_states``."""
         geo = self.geo
@@ -787,6 +905,7 @@ class TextEncoder(_EncoderBase):
         key_lens = klen.to(device=self.device, dtype=torch.int32)
         return self.forward_device(ids, key_lens, slot)
 
+    @_on_stream
     def forward_device(self, ids: torch.Tensor, key_lens: torch.Tensor, slot: int = 0) -> HiddenStates:
         """Same as ``forward`` with inputs already on the device (int32 ids [B,T], int32 key lengths [B]):
         no host synchronisation, so it can be captured into a hipGraph."""

@@ -25,23 +25,28 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_binding_covers_header(built_library):
     from interspeech_ser_amd import _lib
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
-    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 8
 
 
-def test_gemm_args_layout_matches_c(built_library, tmp_path):
-    """The ctypes mirror of ser_gemm_args must have the C compiler's size and offsets."""
-    from interspeech_ser_amd._lib import GemmArgs
-    fields = [f[0] for f in GemmArgs._fields_]
+def test_struct_layouts_match_c(built_library, tmp_path):
+    """Every ctypes mirror (ser_gemm_args, the command-list argument structs, ser_cmd) must have the C
+    compiler's size and field offsets."""
+    from interspeech_ser_amd._lib import STRUCT_MIRRORS
+    lines = []
+    for cname, cls in STRUCT_MIRRORS.items():
+        lines.append(f'printf("{cname}.sizeof %zu\\n", sizeof({cname}));')
+        for f, *_ in cls._fields_:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
     src = tmp_path / "layout.c"
-    body = "\n".join(f'printf("{f} %zu\\n", offsetof(ser_gemm_args, {f}));' for f in fields)
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\n'
-                   f'int main(void){{printf("sizeof %zu\\n", sizeof(ser_gemm_args));{body}return 0;}}\n')
+                   f'int main(void){{' + "".join(lines) + 'return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", str(src), "-o", str(exe)])
     out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
-    assert int(out["sizeof"]) == ctypes.sizeof(GemmArgs)
-    for f in fields:
-        assert int(out[f]) == getattr(GemmArgs, f).offset, f
+    for cname, cls in STRUCT_MIRRORS.items():
+        assert int(out[f"{cname}.sizeof"]) == ctypes.sizeof(cls), cname
+        for f, *_ in cls._fields_:
+            assert int(out[f"{cname}.{f}"]) == getattr(cls, f).offset, (cname, f)
 
 
 def test_argument_errors_are_reported_not_raised(built_library):
