@@ -769,19 +769,34 @@ class WhisperEncoder(_EncoderBase):
                 p + ".fc1", p + ".fc2", k_bias=False, gate=False))        # k_proj has no bias
 
     def _plan(self, lengths, slot: int = 0):
-        key_full = (slot,) + tuple(int(n) for n in lengths)
-        if key_full in self._cache:
-            return self._cache[key_full]
-        key = key_full[1:]
+        """Every Whisper shape is a function of B alone (30 s windows), so buffers are keyed by (slot, B) and a new
+        batch only uploads its B+1 sample offsets."""
+        lengths = tuple(int(n) for n in lengths)
+        pl = self._cache.get((slot, len(lengths)))
+        if pl is None:
+            pl = self._build_plan(len(lengths), slot)
+        if pl["lengths"] != lengths:
+            if pl["offs_evt"] is not None:
+                pl["offs_evt"].synchronize()
+            pl["offs_host"].numpy()[:] = np.concatenate([[0], np.cumsum(lengths)])
+            pl["sample_offs"].copy_(pl["offs_host"], non_blocking=True)
+            pl["offs_evt"] = torch.cuda.Event()
+            pl["offs_evt"].record()
+            pl["lengths"] = lengths
+        return pl
+
+    def _build_plan(self, B: int, slot: int):
+        key_full = (slot, B)
         geo, dev = self.geo, self.device
-        B, D, Fd, nm = len(key), geo.hidden, geo.ffn, geo.n_mels
+        D, Fd, nm = geo.hidden, geo.ffn, geo.n_mels
         T2, T1 = geo.max_source_positions, self.N_FRAMES
         if T1 != 2 * T2:
             raise ValueError("max_source_positions must be 1500 (3000 mel frames / 2)")
         Tp = T1 + 2
         M = B * T2
-        pl = dict(B=B, M=M, lengths=key)
-        pl["sample_offs"] = torch.tensor(np.concatenate([[0], np.cumsum(key)]), dtype=torch.int64, device=dev)
+        pl = dict(B=B, M=M, lengths=None, offs_evt=None)
+        pl["offs_host"] = torch.empty(B + 1, dtype=torch.int64).pin_memory()
+        pl["sample_offs"] = torch.empty(B + 1, dtype=torch.int64, device=dev)
         pl["mel"] = torch.empty((B, nm, T1), dtype=torch.float32, device=dev)
         ws = lib.ser_workspace_bytes(_lib.WS_LOGMEL, B, 0, 0, 0, self.mode)
         pl["work"] = torch.empty(ws, dtype=torch.uint8, device=dev)
@@ -799,7 +814,7 @@ class WhisperEncoder(_EncoderBase):
         pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
         pl["first_groups"] = self._stat_groups(D)
         self._layer_buffers(pl, M, pl["first_groups"])
-        if len(self._cache) >= 2:
+        if len(self._cache) >= 3:
             self._cache.pop(next(iter(self._cache)))
         self._cache[key_full] = pl
         return pl
@@ -807,22 +822,22 @@ class WhisperEncoder(_EncoderBase):
     upload = SpeechEncoder.upload
     download = SpeechEncoder.download
 
-    def log_mel(self, packed_wave: torch.Tensor, lengths: Sequence[int]) -> torch.Tensor:
+    def log_mel(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> torch.Tensor:
         """a16: [B, n_mels, 3000] fp32 input_features, computed on the GPU."""
-        pl = self._plan(lengths)
+        pl = self._plan(lengths, slot)
         check(lib.ser_logmel_whisper(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["B"], self.mel.data_ptr(),
                                      self.geo.n_mels, pl["mel"].data_ptr(), pl["work"].data_ptr(), _stream()),
               "ser_logmel_whisper")
         return pl["mel"]
 
-    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int]) -> HiddenStates:
-        return self.forward_features(self.log_mel(packed_wave, lengths), lengths)
+    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
+        return self.forward_features(self.log_mel(packed_wave, lengths, slot), lengths, slot)
 
     @_on_stream
-    def forward_features(self, input_features: torch.Tensor, lengths: Sequence[int]) -> HiddenStates:
+    def forward_features(self, input_features: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
         """a17: ``model.encoder(input_features, output_hidden_states=True).hidden_states``."""
         geo = self.geo
-        pl = self._plan(lengths)
+        pl = self._plan(lengths, slot)
         B, M, D, nm = pl["B"], pl["M"], geo.hidden, geo.n_mels
         T1, T2 = self.N_FRAMES, geo.max_source_positions
         if tuple(input_features.shape) != (B, nm, T1):

@@ -71,3 +71,17 @@ def test_engine_refuses_to_run_without_a_gpu(built_library):
     from interspeech_ser_amd.engine import SpeechEncoder
     with pytest.raises(SerHipError):
         SpeechEncoder(C.TINY_WAVLM, {}, "cuda:0")
+
+
+def test_command_list_reports_the_failing_entry(built_library):
+    """ser_run validates like the launchers it wraps: a bad entry stops the list and names its index (no GPU needed)."""
+    from interspeech_ser_amd import _lib
+    cmds = (_lib.Cmd * 3)()
+    cmds[0].op = _lib.OP_GEMM                       # null operands -> ser_gemm refuses before any launch
+    failed = ctypes.c_int32(-1)
+    assert _lib.lib.ser_run(cmds, 1, ctypes.byref(failed), None) < 0 and failed.value == 0
+    assert b"ser_gemm" in _lib.lib.ser_last_error()
+    cmds[0].op = 99
+    assert _lib.lib.ser_run(cmds, 1, ctypes.byref(failed), None) < 0
+    assert b"unknown op" in _lib.lib.ser_last_error()
+    assert _lib.lib.ser_run(cmds, 0, None, None) == 0
