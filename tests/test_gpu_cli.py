@@ -38,12 +38,15 @@ def test_speech_driver_config0(tmp_path, capsys):
         n = 48000 if i < 6 else 48000 - 777 * i            # two ragged ones
         waves[f"syn_{i:04d}"] = write_wav(wav_dir / f"syn_{i:04d}.wav", synth(7 + i, n))
     (wav_dir / "broken.wav").write_bytes(b"not a wav file")
+    write_wav(wav_dir / "syn_0003b_tiny.wav", synth(99, 300))       # decodes, but is shorter than the receptive field:
     rc = driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", str(wav_dir), "--save_path", str(out),
                             "--synthetic_weights", "--n_layer", "0", "--batch_size", "5"])
-    text = capsys.readouterr().out
+    text = capsys.readouterr().out                                    # its batch falls back to one-by-one, neighbours survive
     assert rc == 0
-    assert "Using device = cuda" in text and "9 file are going to be processed..." in text
+    assert "Using device = cuda" in text and "10 file are going to be processed..." in text
     assert "Failed to process" in text and "broken.wav" in text      # logged and skipped, like the reference
+    assert "syn_0003b_tiny.wav" in text and "receptive field" in text
+    os.remove(wav_dir / "syn_0003b_tiny.wav")
     files = sorted(os.listdir(out))
     assert files == [f"syn_{i:04d}.pt" for i in range(8)]
     geo = C.WAVLM_LARGE
