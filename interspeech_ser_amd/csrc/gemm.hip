@@ -442,7 +442,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3 };
+enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN512_M64 = 4, CFG_LN512_M32 = 5, CFG_128x64 = 6 };
 
 template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI>
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
@@ -474,7 +474,14 @@ static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
 }
 
 static int pick_cfg(const ser_gemm_args* a) {
-    if (a->ln_gamma) return CFG_LN512;
+    if (a->ln_gamma) {
+        // Row-complete LayerNorm tiles are BM x 512.  The last conv layers have few rows (M = 16k / 8k / 4k for eight
+        // 10 s utterances): 128-row tiles would leave half to 7/8 of the CUs idle, so the tile gets shorter until
+        // the grid covers the chip (measured per layer with tools/gemm_by_layer.py).
+        static const int force_bm = [] { const char* e = getenv("SER_GEMM_LN_BM"); return e ? atoi(e) : 0; }();
+        const int bm = force_bm ? force_bm : (a->M >= 200 * 128 ? 128 : (a->M >= 200 * 64 ? 64 : 32));
+        return bm == 128 ? CFG_LN512 : (bm == 64 ? CFG_LN512_M64 : CFG_LN512_M32);
+    }
     if (a->tile_cfg > 0) return a->tile_cfg - 1;
     // Measured on MI355X (tools/gemm_sweep.py, M = 7984): the simple ring keeps the 128x128 tile
     // (2 blocks/CU) ahead of 256x128 on every N <= 3072 shape; 256x256 wins once it has >= ~2 full
@@ -487,6 +494,9 @@ static int pick_cfg(const ser_gemm_args* a) {
         return e ? atol(e) : 200L;
     }();
     if (a->N >= 256 && t256x256 >= t256_min) return CFG_256x256;
+    // grouped positional conv: 64 output channels per group -> a 128x64 tile wastes no MFMA columns
+    static const int n64 = [] { const char* e = getenv("SER_GEMM_N64"); return e ? atoi(e) : 1; }();
+    if (n64 && a->N <= 64) return CFG_128x64;
     return CFG_128x128;
 }
 
@@ -525,6 +535,9 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     }
     switch (pick_cfg(a)) {
         case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 64, 2, true>(a, s);     // 160 KiB ring, one barrier per 64-deep K tile
+        case CFG_LN512_M64: return launch_cfg<1, 8, 4, 4, 64, 2, true>(a, s);   // 64 x 512 tile, 8 waves of 64x64
+        case CFG_LN512_M32: return launch_cfg<1, 4, 2, 8, 64, 2, true>(a, s);   // 32 x 512 tile, 4 waves of 32x128
+        case CFG_128x64:  return launch_cfg<4, 1, 2, 4, 64, 2, false>(a, s);    // 4 waves of 32x64: a wave owns a whole 64-column stat group
         case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
         case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
         default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
