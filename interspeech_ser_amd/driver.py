@@ -55,6 +55,8 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
                    help="local *.safetensors / pytorch_model.bin (or directory); default: HF cache lookup, "
                         "else seeded synthetic weights")
     p.add_argument("--skip_existing", action="store_true")
+    p.add_argument("--lora_alpha", type=float, default=16.0,
+                   help="LoRA alpha of a fine-tuned --checkpoint (the reference's LoraConfig: r=8, alpha=16)")
     p.add_argument("--timing", action="store_true", help="print where the launching thread spent its time")
     p.add_argument("--compat_layer_quirk", action="store_true",
                    help="speech driver: index hidden_states with the number of files found in --save_path at "
@@ -79,11 +81,12 @@ def resolve_layer_index(n_layer: int, num_states: int) -> int:
 
 
 # ------------------------------------------------------------------------ weights
-def find_weights(ssl_type: str, checkpoint: str, synthetic: bool, seed: int, geo):
-    """Rank 0 only: the other ranks receive the tensors by broadcast (dist.broadcast_state_dict)."""
+def find_weights(ssl_type: str, checkpoint: str, synthetic: bool, seed: int, geo, lora_alpha: float = 16.0):
+    """Rank 0 only: the other ranks receive the tensors by broadcast (dist.broadcast_state_dict).
+    A checkpoint that carries PEFT LoRA adapters (preprocess_speech_pretrained.py:108-177) is merged at load."""
     from .weights import load_checkpoint, synthetic_state_dict
     if checkpoint:
-        return load_checkpoint(checkpoint), f"checkpoint {checkpoint}"
+        return load_checkpoint(checkpoint, lora_alpha), f"checkpoint {checkpoint}"
     if not synthetic:
         # offline HF cache layout: $HF_HOME/hub/models--org--name/snapshots/<rev>/
         home = os.environ.get("HF_HOME", os.path.join(os.path.expanduser("~"), ".cache", "huggingface"))
@@ -113,7 +116,7 @@ class _Extractor:
         if rank == 0:
             try:
                 sd, self.weight_source = find_weights(args.ssl_type, args.checkpoint, args.synthetic_weights,
-                                                      args.seed, self.geo)
+                                                      args.seed, self.geo, args.lora_alpha)
             except OSError as e:
                 err = str(e)
         if D.broadcast_int(1 if (rank == 0 and sd is None) else 0) == 1:

@@ -157,7 +157,43 @@ def normalize_names(sd: StateDict) -> StateDict:
     return out
 
 
-def load_checkpoint(path: str) -> StateDict:
+def merge_lora(sd: StateDict, lora_alpha: float = 16.0) -> StateDict:
+    """Fold PEFT LoRA adapters into their base weights (next row 8f-4).  The reference fine-tunes WavLM with
+    ``LoraConfig(r=8, lora_alpha=16, target_modules=['q_proj','v_proj'])`` inside a classifier wrapper and extracts
+    with ``ssl_model.wavlm.model`` in eval mode (preprocessing/preprocess_speech_pretrained.py:108-177): dropout is
+    inactive, so every adapted Linear computes ``x W^T + (alpha/r) x A^T B^T`` = a plain Linear with
+    ``W + (alpha/r) B A``.  Keys: ``<wrapper>.base_model.model.<name>.base_layer.weight|bias``,
+    ``<name>.lora_A.<adapter>.weight`` [r, in], ``<name>.lora_B.<adapter>.weight`` [out, r]; the classifier head
+    and anything else off the encoder are dropped later by ``normalize_names``.  ``alpha`` is not stored in a
+    state dict (it lives in LoraConfig), hence the argument; r is read from A's shape.  A state dict without
+    adapter keys is returned unchanged."""
+    if not any(".lora_A." in k for k in sd):
+        return sd
+    out: StateDict = {}
+    adapters = {}
+    for k, v in sd.items():
+        k2 = k
+        for wrap in ("wavlm.base_model.model.", "whisper.base_model.model.", "base_model.model."):
+            if k2.startswith(wrap):
+                k2 = k2[len(wrap):]
+                break
+        if ".lora_A." in k2 or ".lora_B." in k2:
+            mod, rest = k2.split(".lora_", 1)
+            adapters.setdefault(mod, {})[rest[0]] = v.detach().to(torch.float64)
+        elif ".lora_dropout" in k2 or ".lora_embedding" in k2 or k2.startswith("classifier."):
+            continue
+        else:
+            out[k2.replace(".base_layer.", ".")] = v
+    for mod, ab in adapters.items():
+        if "A" not in ab or "B" not in ab or mod + ".weight" not in out:
+            raise OSError(f"incomplete LoRA adapter for '{mod}'")
+        a, b = ab["A"], ab["B"]
+        scale = float(lora_alpha) / a.shape[0]
+        out[mod + ".weight"] = (out[mod + ".weight"].detach().to(torch.float64) + scale * (b @ a)).to(torch.float32)
+    return out
+
+
+def load_checkpoint(path: str, lora_alpha: float = 16.0) -> StateDict:
     """Read a local checkpoint file or directory.  Raises ``OSError`` when nothing
     loadable is found -- the error class the reference's driver reports as
     "No pretrained model found" (preprocess_speech.py:115-117)."""
@@ -177,7 +213,7 @@ def load_checkpoint(path: str) -> StateDict:
             sd.update(load_file(fn, device="cpu"))
         else:
             sd.update(torch.load(fn, map_location="cpu", weights_only=True))
-    return normalize_names(sd)
+    return normalize_names(merge_lora(sd, lora_alpha))
 
 
 def state_dict_digest(sd: StateDict) -> str:

@@ -143,3 +143,42 @@ def test_checkpoint_round_trip_with_hub_prefixes(tmp_path):
     assert sorted(back) == sorted(sd) and state_dict_digest(back) == state_dict_digest(sd)
     with pytest.raises(OSError):
         load_checkpoint(str(tmp_path / "nothing_here"))
+
+
+def test_lora_adapters_are_merged_at_load(tmp_path):
+    """Next row 8f-4: a PEFT-wrapped fine-tuned checkpoint (preprocess_speech_pretrained.py:108-177: r=8, alpha=16 on
+    q_proj / v_proj, classifier head on top) loads as plain HF names with W + (alpha/r) B A -- the algebraic identity
+    of an eval-mode LoRA Linear -- and a checkpoint without adapters is untouched."""
+    import torch
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.weights import load_checkpoint, merge_lora, synthetic_state_dict
+    geo = C.TINY_WAVLM
+    base = synthetic_state_dict(geo, 9)
+    g = torch.Generator().manual_seed(4)
+    wrapped, want = {}, dict(base)
+    for k, v in base.items():
+        mod = k.rsplit(".", 1)[0]
+        if mod.endswith(("q_proj", "v_proj")):
+            wrapped[f"wavlm.base_model.model.{mod}.base_layer.{k.rsplit('.', 1)[1]}"] = v
+            if k.endswith(".weight"):
+                a, b = torch.randn(8, v.shape[1], generator=g), torch.randn(v.shape[0], 8, generator=g) * 0.1
+                wrapped[f"wavlm.base_model.model.{mod}.lora_A.default.weight"] = a
+                wrapped[f"wavlm.base_model.model.{mod}.lora_B.default.weight"] = b
+                want[k] = (v.double() + 2.0 * (b.double() @ a.double())).float()
+        else:
+            wrapped["wavlm.base_model.model." + k] = v
+    wrapped["classifier.0.weight"] = torch.randn(512, geo.hidden, generator=g)
+    path = tmp_path / "whisper_lora_ser.pt"
+    torch.save(wrapped, path)
+    got = load_checkpoint(str(path))
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    x = torch.randn(5, geo.hidden, generator=g)                      # the identity itself, on one adapted Linear
+    k = "encoder.layers.0.attention.q_proj"
+    a, b = wrapped[f"wavlm.base_model.model.{k}.lora_A.default.weight"], wrapped[f"wavlm.base_model.model.{k}.lora_B.default.weight"]
+    lora_out = x @ base[k + ".weight"].T + (16 / 8) * (x @ a.T) @ b.T
+    assert torch.allclose(x @ got[k + ".weight"].T, lora_out, atol=1e-4)
+    assert merge_lora(base) is base
+    half = load_checkpoint(str(path), lora_alpha=8.0)                # alpha is configuration, not stored in the file
+    assert torch.allclose(half[k + ".weight"], (base[k + ".weight"] + want[k + ".weight"]) / 2, atol=1e-6)
