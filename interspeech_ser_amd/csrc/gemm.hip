@@ -367,6 +367,10 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
         }
     } else {
+        // wave-uniform feature flags: the column scale and the row partial sums cost 2 VALU each per element, and
+        // most launches use neither (the epilogue is VALU-bound where it carries a GELU)
+        const bool do_scale = p.col_scale_end > 0;
+        const bool do_stat = p.stat_out != nullptr;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
             const int m = m0 + wm * TM * 16 + mi * 16 + frow;
@@ -388,7 +392,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     const int nj = ni + (r >> 2), rr = r & 3;
                     // LN(x) W^T = rstd * (x W'^T - mu * colsum(W')) + (beta W^T + b)
                     float x = fmaf(rs, acc[nj][mi][rr] - mu * csum[nj * 4 + rr], bias[nj * 4 + rr]);
-                    if (ncol0 + nj * 16 < p.col_scale_end) x *= p.col_scale;       // e.g. q *= dh^-0.5 * log2(e)
+                    if (do_scale && ncol0 + nj * 16 < p.col_scale_end) x *= p.col_scale;   // e.g. q *= dh^-0.5 * log2(e)
                     v[r] = x;
                 }
                 if (p.act == SER_ACT_GELU) {
@@ -406,11 +410,11 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
                     v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
                 }
-                if (ok0) {
+                if (do_stat && ok0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
                 }
-                if (ok1) {
+                if (do_stat && ok1) {
 #pragma unroll
                     for (int r = 4; r < 8; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
                 }
