@@ -275,3 +275,26 @@ def test_pipelined_slots_equal_synchronous_path():
         assert len(g) == len(w)
         for a, b in zip(g, w):
             assert a.shape == b.shape and torch.equal(a, b), k
+
+
+def test_command_list_replay_equals_launch_by_launch():
+    """A forward replayed from its recorded command list (ser_run, sizes patched per batch) is bit-identical to the
+    same forward launched kernel by kernel, across growing / shrinking ragged batches that re-use one arena."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_HUBERT
+    sd = synthetic_state_dict(geo, 5)
+    taped = SpeechEncoder(geo, sd, "cuda:0", mode="bf16")
+    eager = SpeechEncoder(geo, sd, "cuda:0", mode="bf16")
+    eager.use_tape = False
+    rng = np.random.default_rng(11)
+    for k in range(5):
+        lens = [int(n) for n in rng.integers(400, 40000, size=int(rng.integers(1, 7)))]
+        waves = [synth_wave(10 * k + i, n) for i, n in enumerate(lens)]
+        a = taped.forward(taped.upload(waves), lens)
+        b = eager.forward(eager.upload(waves), lens)
+        torch.cuda.synchronize()
+        assert a.frame_offs == b.frame_offs
+        assert torch.equal(a.states, b.states), k
+    assert taped._arenas[0].get("tape") is not None and eager._arenas[0].get("tape") is None
