@@ -175,9 +175,10 @@ def main():
 
     # The batch is processed as `micro` utterance groups (parallel branches of one hipGraph): every
     # launch of the step, timed or traced, has the group's shape.
-    micro = args.micro if (args.micro > 1 and args.batch % args.micro == 0) else 1
-    per = args.batch // micro
-    groups = [(enc.upload(waves[i * per:(i + 1) * per]), lengths[i * per:(i + 1) * per]) for i in range(micro)]
+    micro = args.micro if 1 < args.micro <= args.batch else 1
+    per = -(-args.batch // micro)                                   # uneven splits allowed: 16 -> 6 + 5 + 5
+    cuts = [round(i * args.batch / micro) for i in range(micro + 1)]
+    groups = [(enc.upload(waves[a:b]), lengths[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
     torch.cuda.synchronize()
 
     def eager_step():

@@ -24,9 +24,10 @@
 //     units XOR-swizzled so the 4 keys of a transposed read hit 4 different bank quarters.
 //   * FP32X mode: every product is the 3-term bf16 split (hi*hi + lo*hi + hi*lo).
 #include "ser_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
-#define ABQ 128      // query rows per block
+#define ABQ 128      // query rows per 4-wave block (an 8-wave block takes 256)
 #define ABKV 64      // keys per tile
 #define LOG2E 1.4426950408889634f
 
@@ -59,15 +60,19 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 
 // TBL: a relative-position bias table is present (WavLM) -- compile-time, so the plain path carries no bias code
 // and the bias path does not zero accumulators it is about to overwrite.
-template <int DHP, int MODE, bool PRE, bool TBL>
-__global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2) void attention_kernel(const AttnParams p) {
+// NWV waves (x 32 queries) per block.  8 waves halve the K/V global->LDS traffic and the bias-row copies per query:
+// used for bf16 head dims <= 64 once an utterance has more than one 128-query tile.
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2))
+void attention_kernel(const AttnParams p) {
+    constexpr int NT = 64 * NWV;                // threads per block
     constexpr int NP = (MODE == SER_MODE_FP32X) ? 2 : 1;
     constexpr int RS = DHP * 2;                 // LDS row bytes
     constexpr int KS = DHP / 16;                // QK^T k-steps
     constexpr int DSUB = DHP / 32;              // 32-wide output column blocks
     constexpr int CPR = DHP / 8;                // 16-byte chunks per row
     constexpr int TILE = ABKV * RS;             // bytes of one K or V plane tile
-    constexpr int NCH = ABKV * CPR / 256;       // staged 16-B chunks per thread per plane per operand
+    constexpr int NCH = ABKV * CPR / NT;        // staged 16-B chunks per thread per plane per operand
     constexpr bool DB = (NCH * 2 * NP) <= 8;    // double-buffer when the register stage is <= 32 VGPRs
     constexpr int NBUF = DB ? 2 : 1;
     constexpr int BUF = 2 * NP * TILE;          // one K+V buffer
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
     const int h = bh % p.H, b = bh / p.H;
     const int row0 = p.frame_offs[b];
     const int T = p.frame_offs[b + 1] - row0;
-    const int q0 = qt * ABQ;
+    const int q0 = qt * (32 * NWV);
     if (q0 >= T) return;
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
     auto stage_load = [&](int kt, bool masked) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NT;
             const int key = c / CPR, ch = c - key * CPR;
             const int kg = kt * ABKV + key;
             // branch-free: always load from a valid address, zero by select (keys >= T, pad columns >= dh)
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
         char* base = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NT;
             const int key = c / CPR, ch = c - key * CPR;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
@@ -172,16 +177,16 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
         // scattered into the 4 shifted copies; indices past 2T-1 are written as zeros (tail padding)
         const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T);
         const int n = 2 * T - 1, span = p.bias_stride + 3;
-        for (int base = 0; base < span; base += 5 * 256) {
+        for (int base = 0; base < span; base += 5 * NT) {
             float v[5];
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
-                const int idx = base + u * 256 + tid;
+                const int idx = base + u * NT + tid;
                 v[u] = idx < n ? trow[idx] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
-                const int idx = base + u * 256 + tid;
+                const int idx = base + u * NT + tid;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int j = idx - c;
@@ -412,16 +417,16 @@ __global__ __launch_bounds__(256, (DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2
     }
 }
 
-template <int DHP, int MODE, bool PRE, bool TBL>
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE, PRE, TBL>;
+    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV>;
     static bool ready = false;
     if (lds > 65536 && !ready) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return ser_fail((int)e, "ser_attention: cannot raise dynamic LDS");
         ready = true;
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, grid, dim3(64 * NWV), lds, s, p);
     return ser_check_launch("ser_attention");
 }
 
@@ -442,7 +447,11 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     if (table && table_T < max_frames) return ser_fail(-7, "ser_attention: bias table built for T=%d < max_frames=%d", table_T, max_frames);
     const int dhp = dh <= 64 ? 64 : 128;
     const int np = mode == SER_MODE_FP32X ? 2 : 1;
-    const int nch = ABKV * (dhp / 8) / 256;
+    // 8-wave blocks: -1.1 us per launch in isolation (24.4 -> 23.3 us at 8 x 499 frames), +1.2 % on the real step
+    // (512-thread blocks leave no room for the other utterance group's blocks on the CU): off unless SER_ATTN_W8=1
+    static const int w8_knob = [] { const char* e = getenv("SER_ATTN_W8"); return e ? atoi(e) : 0; }();
+    const int nwv = (w8_knob && np == 1 && dhp == 64 && max_frames > ABQ) ? 8 : 4;
+    const int nch = ABKV * (dhp / 8) / (64 * nwv);
     const int nbuf = (nch * 2 * np <= 8) ? 2 : 1;
     // copy stride == 16 (mod 64) floats: the 4 shifted copies x the 4 query phases of a ds_read_b128
     // lane group then land on 16 distinct 4-bank slots (a multiple of 64 made them 2-way conflicts)
@@ -460,12 +469,15 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     p.gru_const = gru_const; p.gate_col = gate_col;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
-    p.B = B; p.nq = (max_frames + ABQ - 1) / ABQ;
+    p.B = B; p.nq = (max_frames + 32 * nwv - 1) / (32 * nwv);
     dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * p.nq), 1, 1);
     hipStream_t s = (hipStream_t)stream;
     const bool pre = scale <= 0.f;
 #define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
                               : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
+    if (dhp == 64 && np == 1 && nwv == 8)
+        return pre ? (table ? launch_attention<64, SER_MODE_BF16, true, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, true, false, 8>(p, grid, lds, s))
+                   : (table ? launch_attention<64, SER_MODE_BF16, false, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, false, false, 8>(p, grid, lds, s));
     if (dhp == 64 && np == 1) return SER_ATTN(64, SER_MODE_BF16);
     if (dhp == 64) return SER_ATTN(64, SER_MODE_FP32X);
     if (np == 1) return SER_ATTN(128, SER_MODE_BF16);
