@@ -9,6 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: torch brings its own libamdhip64; libserhip must bind to that copy, not load a second
+#                              HIP runtime beside it (with the library loaded first, launches fail with "no ROCm-capable device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SER_HIP_LIB") or os.path.join(_HERE, "lib", "libserhip.so")   # override: A/B builds (tools/)
 
