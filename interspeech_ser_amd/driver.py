@@ -55,6 +55,8 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
                    help="local *.safetensors / pytorch_model.bin (or directory); default: HF cache lookup, "
                         "else seeded synthetic weights")
     p.add_argument("--skip_existing", action="store_true")
+    p.add_argument("--resample", action="store_true",
+                   help="accept non-16 kHz wav files through a polyphase resampler (parity with librosa's soxr_hq unpinned)")
     p.add_argument("--lora_alpha", type=float, default=16.0,
                    help="LoRA alpha of a fine-tuned --checkpoint (the reference's LoraConfig: r=8, alpha=16)")
     p.add_argument("--timing", action="store_true", help="print where the launching thread spent its time")
@@ -256,7 +258,7 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
 
     def decode(path):
         try:
-            return path, load_wav_16k(path), None
+            return path, load_wav_16k(path, resample=args.resample), None
         except Exception as e:                            # noqa: BLE001  (reference: except Exception -> print)
             return path, None, e
 

@@ -23,12 +23,14 @@ class UnsupportedAudio(ValueError):
     pass
 
 
-def load_wav_16k(path: str) -> np.ndarray:
+def load_wav_16k(path: str, resample: bool = False) -> np.ndarray:
     """Decode a RIFF/WAVE file to mono float32 in [-1, 1] the way soundfile (behind
     ``librosa.load``) does: integer PCM / 2^(bits-1), channels averaged.
-    Only 16 kHz input is accepted: the reference resamples other rates with soxr_hq
-    (librosa 0.10.1), which is not restated here -- such files raise
-    and the driver logs "Failed to process" exactly like any other per-file error."""
+    16 kHz input is bit-faithful to the reference.  Other rates: the reference resamples with soxr_hq
+    (librosa 0.10.1), which is not available offline and not restated -- by default such
+    files raise and the driver logs "Failed to process" like any other per-file error; with
+    ``resample=True`` (driver flag ``--resample``) they go through a Kaiser-windowed polyphase filter
+    (``scipy.signal.resample_poly``): usable features, but PARITY UNPINNED against the reference's resampler."""
     try:
         with _wave.open(path, "rb") as wf:
             sr, ch, width, n = wf.getframerate(), wf.getnchannels(), wf.getsampwidth(), wf.getnframes()
@@ -58,7 +60,13 @@ def load_wav_16k(path: str) -> np.ndarray:
     if ch > 1:
         x = x.reshape(-1, ch).mean(axis=1).astype(np.float32)
     if sr != TARGET_SR:
-        raise UnsupportedAudio(f"sample rate {sr} Hz: only {TARGET_SR} Hz input is supported (no resampler)")
+        if not resample:
+            raise UnsupportedAudio(f"sample rate {sr} Hz: only {TARGET_SR} Hz input is supported (pass --resample for a "
+                                   f"polyphase resampler whose parity with librosa's soxr_hq is unpinned)")
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(sr), TARGET_SR)
+        x = resample_poly(x.astype(np.float64), TARGET_SR // g, int(sr) // g, window=("kaiser", 14.0)).astype(np.float32)
     return np.ascontiguousarray(x, dtype=np.float32)
 
 

@@ -182,3 +182,24 @@ def test_lora_adapters_are_merged_at_load(tmp_path):
     assert merge_lora(base) is base
     half = load_checkpoint(str(path), lora_alpha=8.0)                # alpha is configuration, not stored in the file
     assert torch.allclose(half[k + ".weight"], (base[k + ".weight"] + want[k + ".weight"]) / 2, atol=1e-6)
+
+
+def test_opt_in_resampler_keeps_pitch_and_length(tmp_path):
+    """Next row 8f-3 (opt-in, parity unpinned): a 44.1 kHz file is refused by default and, with resample=True, comes out
+    at 16 kHz with the right length and the same tone."""
+    import wave
+    import pytest
+    from interspeech_ser_amd import frontend
+    sr, secs, f0 = 44100, 1.0, 440.0
+    t = np.arange(int(sr * secs)) / sr
+    pcm = (0.5 * np.sin(2 * np.pi * f0 * t) * 32767).astype("<i2")
+    with wave.open(str(tmp_path / "hi.wav"), "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(sr); wf.writeframes(pcm.tobytes())
+    with pytest.raises(frontend.UnsupportedAudio):
+        frontend.load_wav_16k(str(tmp_path / "hi.wav"))
+    y = frontend.load_wav_16k(str(tmp_path / "hi.wav"), resample=True)
+    assert y.dtype == np.float32 and abs(len(y) - 16000) <= 1
+    spec = np.abs(np.fft.rfft(y * np.hanning(len(y))))
+    assert abs(np.argmax(spec) * 16000.0 / len(y) - f0) < 2.0
+    ref = 0.5 * np.sin(2 * np.pi * f0 * np.arange(len(y)) / 16000.0)
+    assert float(np.abs(y[200:-200] - ref[200:-200]).max()) < 2e-3
