@@ -501,6 +501,12 @@ static int pick_cfg(const ser_gemm_args* a) {
     // grouped positional conv: 64 output channels per group -> a 128x64 tile wastes no MFMA columns
     static const int n64 = [] { const char* e = getenv("SER_GEMM_N64"); return e ? atoi(e) : 1; }();
     if (n64 && a->N <= 64) return CFG_128x64;
+    // Deep-K, narrow-N GEMMs (FC2: N = D, K = 4D) that are too small for the 256x256 tile: 256x128 tiles are SLOWER
+    // in isolation (52 -> 64 us at M = 3992: only 128 blocks) but +1.5 % on the real step in five A/B pairs -- the
+    // launch then occupies half the CUs for its whole (long) K loop and the other utterance group's kernels own the
+    // other half, instead of both time-slicing every CU.  The shallow out-projection (K = D) loses with it.
+    static const int deepk = [] { const char* e = getenv("SER_GEMM_DEEPK_256x128"); return e ? atoi(e) : 1; }();
+    if (deepk && a->groups == 1 && a->K >= 2048 && a->N >= 128 && a->M >= 512) return CFG_256x128;
     return CFG_128x128;
 }
 
