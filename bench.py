@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip per-launch GEMM events")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--split", type=str, default="", help="explicit utterance-group sizes, e.g. 9,7 (overrides --micro)")
     ap.add_argument("--micro", type=int, default=2,
                     help="split the batch into this many utterance groups run as parallel graph branches")
     args = ap.parse_args()
@@ -178,6 +179,11 @@ def main():
     micro = args.micro if 1 < args.micro <= args.batch else 1
     per = -(-args.batch // micro)                                   # uneven splits allowed: 16 -> 6 + 5 + 5
     cuts = [round(i * args.batch / micro) for i in range(micro + 1)]
+    if args.split:                                                  # explicit group sizes, e.g. --split 9,7
+        sizes = [int(x) for x in args.split.split(",")]
+        assert sum(sizes) == args.batch and min(sizes) > 0, "--split must add up to --batch"
+        micro, cuts = len(sizes), [sum(sizes[:i]) for i in range(len(sizes) + 1)]
+        per = max(sizes)
     groups = [(enc.upload(waves[a:b]), lengths[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
     torch.cuda.synchronize()
 

@@ -25,6 +25,7 @@
 //     of tiles that share activation panels.
 #include "ser_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -492,6 +493,24 @@ static int pick_cfg(const ser_gemm_args* a) {
     // rounds of blocks (N = 4096, conv layers) because it halves the L2->LDS bytes per FLOP.
     // In the real step (two utterance groups in flight) 256x256 already pays from ~200 tiles (QKV and FC1
     // at M = 3992): 9.6 -> 9.1 ms per step, A/B on one device.
+    {   // experiments: SER_GEMM_FORCE="N:K:cfg[,N:K:cfg...]" pins the tile config of matching launches (tools/)
+        struct Rule { int n, k, cfg; };
+        static Rule rules[8];
+        static const int nrules = [] {
+            const char* e = getenv("SER_GEMM_FORCE");
+            int n = 0;
+            while (e && *e && n < 8) {
+                int a0, a1, a2, used = 0;
+                if (sscanf(e, "%d:%d:%d%n", &a0, &a1, &a2, &used) != 3) break;
+                rules[n++] = {a0, a1, a2};
+                e += used;
+                if (*e == ',') ++e;
+            }
+            return n;
+        }();
+        for (int i = 0; i < nrules; ++i)
+            if (rules[i].n == a->N && rules[i].k == a->K && rules[i].cfg >= 0 && rules[i].cfg <= CFG_256x256) return rules[i].cfg;
+    }
     const long t256x256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
     static const long t256_min = [] {                   // tuning knob (tools/): SER_GEMM_T256_MIN=<tiles>
         const char* e = getenv("SER_GEMM_T256_MIN");
