@@ -20,7 +20,7 @@ for i in range(n):
     secs += L / 16000
 t0 = time.perf_counter()
 driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", wav_dir, "--save_path", out, "--synthetic_weights",
-                   "--mode", mode, "--batch_size", os.environ.get("BS", "16"), "--num_workers", os.environ.get("NW", "8"), "--timing"])
+                   "--mode", mode, "--batch_size", os.environ.get("BS", "16"), "--num_workers", os.environ.get("NW", "4"), "--timing"])
 dt = time.perf_counter() - t0
 print(f"E2E {n} files ({secs:.0f} s audio) incl. weight init: {dt:.1f} s; files written: {len(os.listdir(out))}")
 shutil.rmtree(root)
