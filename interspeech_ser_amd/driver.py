@@ -22,12 +22,10 @@ Deliberate, documented differences:
 from __future__ import annotations
 
 import argparse
-import math
 import os
-import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch

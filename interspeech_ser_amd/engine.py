@@ -18,7 +18,6 @@ exist, so no attention / conv masking is needed) and waste no FLOPs on padding.
 from __future__ import annotations
 
 import ctypes as C
-import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
