@@ -112,9 +112,11 @@ def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("M,N,K,bias", [(300, 512, 192, True), (1000, 512, 1536, False), (77, 64, 128, True)])
+@pytest.mark.parametrize("M,N,K,bias", [(300, 512, 192, True), (1000, 512, 1536, False), (77, 64, 128, True),
+                                        (13001, 512, 128, True), (25999, 512, 64, False)])
 def test_gemm_layernorm_gelu_epilogue(L, mode, M, N, K, bias):
-    """Conv-stack epilogue: act(LayerNorm_row(acc + bias)) over the full (<= 512 wide) row."""
+    """Conv-stack epilogue: act(LayerNorm_row(acc + bias)) over the full (<= 512 wide) row.  The row counts pick all
+    three row-complete tiles in bf16 mode (32 x 512 below 12 800 rows, 64 x 512 below 25 600, 128 x 512 above)."""
     g = torch.Generator().manual_seed(N + K)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -685,3 +687,15 @@ def test_ragged_index_tables_match_numpy(L, step, mult, div):
                                    torch.cuda.current_stream().cuda_stream))
     got = out.cpu().numpy()
     assert np.array_equal(got[:-3], want) and (got[-3:] == -7).all()
+
+
+def test_gemm_deep_k_dispatch_is_exact(L):
+    """Auto dispatch of a deep-K, narrow-N launch (the FC2 shape class -> 256x128 tiles): integer-exact like every
+    forced configuration."""
+    M, N, K = 777, 384, 2048
+    g = torch.Generator().manual_seed(5)
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    W = torch.randint(-2, 3, (N, K), generator=g).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    out, _ = run_gemm(L, to_act(A, 1), to_act(W, 1), M, N, K, 1, bias=bias.to(DEV))
+    assert torch.equal(out.cpu().double(), A.double() @ W.double().T + bias.double())
