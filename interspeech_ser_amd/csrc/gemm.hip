@@ -290,7 +290,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         __syncthreads();
         float* red = (float*)lds;                                     // [BM][WN][2]
         const float invN = 1.0f / (float)p.N;
-        float mean[TM], rstd[TM];
+        float mean[TM], rstd[TM], nmr[TM];
         // one exchange: per-row (sum, sum of squares) partials of the WN waves of a block row.
         // (fp32 accumulators, |mean| << std for conv outputs: E[x^2]-mean^2 is safe here)
 #pragma unroll
@@ -322,6 +322,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
             mean[mi] = s1 * invN;
             rstd[mi] = rsqrtf(fmaxf(s2 * invN - mean[mi] * mean[mi], 0.f) + p.ln_eps);
+            nmr[mi] = -mean[mi] * rstd[mi];                            // (x - mean) * rstd = fma(x, rstd, nmr)
         }
         float lg[CPL], lb[CPL];
 #pragma unroll
@@ -346,7 +347,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int nj = ni + (r >> 2), rr = r & 3;
-                    v[r] = (acc[nj][mi][rr] - mean[mi]) * rstd[mi] * lg[nj * 4 + rr] + lb[nj * 4 + rr];
+                    v[r] = fmaf(fmaf(acc[nj][mi][rr], rstd[mi], nmr[mi]), lg[nj * 4 + rr], lb[nj * 4 + rr]);   // 2 FMAs
                 }
                 if (p.act == SER_ACT_GELU) {
 #pragma unroll
