@@ -69,6 +69,18 @@ def test_speech_driver_config0(tmp_path, capsys):
         ref = O.extract_speech(geo, sd, waves["syn_0001"], layer_index=8)
     assert float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
 
+    # --use_average y through the two-slot pipeline (mean of the last four states, preprocess_speech.py:52-63)
+    out_avg = tmp_path / "feats_avg"
+    rc = driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", str(wav_dir), "--save_path", str(out_avg),
+                            "--synthetic_weights", "--use_average", "y", "--batch_size", "3"])
+    assert rc == 0 and len(os.listdir(out_avg)) == 8
+    for name in ("syn_0002", "syn_0006"):
+        got = torch.load(out_avg / f"{name}.pt")
+        with torch.no_grad():
+            ref = O.extract_speech(geo, sd, waves[name], use_average=True)
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
+
 
 def test_whisper_driver_crop(tmp_path, capsys):
     from interspeech_ser_amd import config as C
