@@ -19,6 +19,7 @@ FAMILY_WAV2VEC2 = "wav2vec2"
 FAMILY_HUBERT = "hubert"
 FAMILY_WHISPER = "whisper"
 FAMILY_ROBERTA = "roberta"      # text side of the bimodal heads (next row 8f-1)
+FAMILY_DEBERTA = "deberta"      # DeBERTa-v2/v3 variant of the text side: ORACLE + fixtures only so far (no HIP path yet)
 
 SPEECH_FAMILIES = (FAMILY_WAVLM, FAMILY_WAV2VEC2, FAMILY_HUBERT)
 
@@ -50,6 +51,8 @@ class EncoderGeometry:
     max_positions: int = 514
     pad_token_id: int = 1
     type_vocab_size: int = 1
+    # DeBERTa-v2/v3 disentangled attention (log-bucketed relative positions, shared q/k projections for positions)
+    position_buckets: int = 256
     name: str = ""
 
     @property
@@ -118,6 +121,11 @@ def tiny_geometry(family: str, *, hidden: int = 128, heads: int = 2, layers: int
     if family == FAMILY_ROBERTA:
         return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads, ffn=ffn,
                                vocab_size=300, max_positions=90, name=f"tiny-{family}-d{hidden}h{heads}")
+    if family == FAMILY_DEBERTA:
+        # 16 buckets: relative distances beyond +-8 are log-bucketed already at 80 tokens, like +-128 at 512 in v3-large
+        return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads, ffn=ffn, vocab_size=300,
+                               max_positions=512, pad_token_id=0, type_vocab_size=0, layer_norm_eps=1e-7,
+                               position_buckets=16, name=f"tiny-{family}-d{hidden}h{heads}")
     if family == FAMILY_WHISPER:
         return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads,
                                ffn=ffn, n_mels=128, max_source_positions=1500,
@@ -154,3 +162,4 @@ TINY_WAV2VEC2 = tiny_geometry(FAMILY_WAV2VEC2, hidden=960, heads=8, ffn=512, pos
 TINY_HUBERT = tiny_geometry(FAMILY_HUBERT, hidden=320, heads=4, ffn=384, pos_groups=4)
 TINY_WHISPER = tiny_geometry(FAMILY_WHISPER, hidden=128, heads=2, ffn=256)
 TINY_ROBERTA = tiny_geometry(FAMILY_ROBERTA, hidden=128, heads=2, ffn=256)
+TINY_DEBERTA = tiny_geometry(FAMILY_DEBERTA, hidden=128, heads=2, ffn=256)

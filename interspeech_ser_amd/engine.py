@@ -957,6 +957,9 @@ def mean_last4(hs: HiddenStates) -> torch.Tensor:
 
 
 def build_encoder(geo: EncoderGeometry, state_dict, device="cuda:0", mode="bf16"):
+    if geo.family == "deberta":
+        raise NotImplementedError("DeBERTa: only the CPU oracle and its fixture exist so far (oracle/ssl_oracle.py); "
+                                  "the HIP path needs a per-(batch, head) 2-D bias mode in ser_attention")
     if geo.family == FAMILY_ROBERTA:
         return TextEncoder(geo, state_dict, device, mode)
     if geo.family == FAMILY_WHISPER:

@@ -21,7 +21,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
+from .config import EncoderGeometry, FAMILY_DEBERTA, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
 StateDict = Dict[str, torch.Tensor]
 
@@ -72,6 +72,22 @@ def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
             _linear(sd, r, p + ".attention.self.query", D, D, gain=1.6)
             _linear(sd, r, p + ".attention.self.key", D, D, gain=1.6)
             _linear(sd, r, p + ".attention.self.value", D, D)
+            _linear(sd, r, p + ".attention.output.dense", D, D)
+            _layer_norm(sd, r, p + ".attention.output.LayerNorm", D)
+            _linear(sd, r, p + ".intermediate.dense", Fd, D)
+            _linear(sd, r, p + ".output.dense", D, Fd)
+            _layer_norm(sd, r, p + ".output.LayerNorm", D)
+        return sd
+    if geo.family == FAMILY_DEBERTA:       # HF DebertaV2Model names (v3 settings: shared q/k position projections)
+        sd["embeddings.word_embeddings.weight"] = r.normal(geo.vocab_size, D, std=0.5)
+        _layer_norm(sd, r, "embeddings.LayerNorm", D)
+        sd["encoder.rel_embeddings.weight"] = r.normal(2 * geo.position_buckets, D, std=0.4)
+        _layer_norm(sd, r, "encoder.LayerNorm", D)
+        for i in range(geo.num_layers):
+            p = f"encoder.layer.{i}"
+            _linear(sd, r, p + ".attention.self.query_proj", D, D, gain=1.6)
+            _linear(sd, r, p + ".attention.self.key_proj", D, D, gain=1.6)
+            _linear(sd, r, p + ".attention.self.value_proj", D, D)
             _linear(sd, r, p + ".attention.output.dense", D, D)
             _layer_norm(sd, r, p + ".attention.output.LayerNorm", D)
             _linear(sd, r, p + ".intermediate.dense", Fd, D)

@@ -173,6 +173,43 @@ def roberta_case(tag, geo, seed):
     np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **rec)
 
 
+def deberta_case(tag, geo, seed):
+    """DeBERTa-v3-style fixture (oracle + golden only: the HIP path for disentangled attention is not built yet)."""
+    import transformers as tf
+    sd = synthetic_state_dict(geo, seed)
+    cfg = tf.DebertaV2Config(vocab_size=geo.vocab_size, hidden_size=geo.hidden, num_hidden_layers=geo.num_layers,
+                             num_attention_heads=geo.heads, intermediate_size=geo.ffn, hidden_act="gelu",
+                             max_position_embeddings=geo.max_positions, type_vocab_size=0, layer_norm_eps=geo.layer_norm_eps,
+                             pad_token_id=geo.pad_token_id, relative_attention=True, position_buckets=geo.position_buckets,
+                             norm_rel_ebd="layer_norm", share_att_key=True, pos_att_type=["p2c", "c2p"],
+                             position_biased_input=False, max_relative_positions=-1,
+                             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = tf.DebertaV2Model(cfg).eval()
+    load_into(model, sd)
+    max_len = 80
+    rng = np.random.default_rng(seed)
+    rec = {"seed": seed, "digest": state_dict_digest(sd), "max_len": np.array(max_len)}
+    worst = 0.0
+    for j, n in enumerate((80, 37, 5)):
+        ids = np.full(max_len, geo.pad_token_id, dtype=np.int64)
+        ids[:n] = rng.integers(3, geo.vocab_size, n)
+        ids[0], ids[n - 1] = 1, 2
+        mask = (np.arange(max_len) < n).astype(np.int64)
+        with torch.no_grad():
+            out = model(input_ids=torch.from_numpy(ids)[None], attention_mask=torch.from_numpy(mask)[None],
+                        output_hidden_states=True)             # preprocess_deroberta.py:57,68 (same calls as roberta)
+        hs = [h.squeeze(0) for h in out.hidden_states]
+        assert torch.equal(hs[-1], out.last_hidden_state.squeeze(0))
+        ours = O.deberta_hidden_states(geo, sd, torch.from_numpy(ids), torch.from_numpy(mask))
+        for a, b in zip(ours, hs):
+            worst = max(worst, float((a - b).abs().max() / max(1.0, float(b.abs().max()))))
+        rec[f"ids_{j}"], rec[f"mask_{j}"] = ids, mask
+        rec[f"states_{j}"] = torch.stack(hs).numpy().astype(np.float32)
+    print(f"{tag}: oracle vs HF rel-max err {worst:.2e}")
+    assert worst < 2e-5, worst
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **rec)
+
+
 def integer_tables():
     import transformers as tf
     geo = C.WAVLM_LARGE
@@ -227,6 +264,9 @@ def full_size_pins():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "deberta":
+        deberta_case("tiny_deberta_d128h2", C.TINY_DEBERTA, 17)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "roberta":       # add the text fixture without touching the others
         roberta_case("tiny_roberta_d128h2", C.TINY_ROBERTA, 15)
         return
@@ -237,6 +277,7 @@ def main():
     speech_case("tiny_hubert_d320h4", C.TINY_HUBERT, 13, ragged)
     whisper_case("tiny_whisper_d128h2", C.TINY_WHISPER, 14, [16000, 100000])
     roberta_case("tiny_roberta_d128h2", C.TINY_ROBERTA, 15)
+    deberta_case("tiny_deberta_d128h2", C.TINY_DEBERTA, 17)
     full_size_pins()
 
 

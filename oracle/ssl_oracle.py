@@ -333,6 +333,65 @@ def roberta_hidden_states(geo, sd: StateDict, input_ids: Tensor, attention_mask:
     return states
 
 
+# ------------------------------------------------- DeBERTa-v2/v3 variant of next row 8f-1 (oracle + fixtures only)
+def deberta_log_bucket(rel: Tensor, bucket_size: int, max_position: int) -> Tensor:
+    """Signed relative distance -> bucket (HF modeling_deberta_v2.py make_log_bucket_position): distances inside
+    +-bucket_size/2 keep their value, larger ones are spaced logarithmically up to max_position."""
+    mid = bucket_size // 2
+    sign = torch.sign(rel)
+    inside = (rel < mid) & (rel > -mid)
+    a = torch.where(inside, torch.full_like(rel, mid - 1), rel.abs()).to(torch.float32)
+    logp = torch.ceil(torch.log(a / mid) / math.log((max_position - 1) / mid) * (mid - 1)) + mid
+    return torch.where(a <= mid, rel.to(torch.float32), logp * sign).to(torch.long)
+
+
+def deberta_hidden_states(geo, sd: StateDict, input_ids: Tensor, attention_mask: Tensor) -> List[Tensor]:
+    """[T] ids + [T] 0/1 mask -> L+1 states [T, D] of DebertaV2Model in its v3 configuration (what AutoModel builds for
+    preprocessing/preprocess_deroberta.py:106-107): no absolute positions, no token types; embeddings = LayerNorm(word) * mask;
+    disentangled attention = (content.content + content->position + position->content) / sqrt(3 dh) with the q/k
+    projections shared between content and the LayerNorm-ed relative embeddings (share_att_key), relative distances
+    log-bucketed; a (query, key) pair is attendable only if BOTH are real tokens, everything else is filled with the
+    dtype minimum (so a padded query row is a uniform average over all T keys); post-LayerNorm BERT blocks.
+    HF modeling_deberta_v2.py: DebertaV2Embeddings, DebertaV2Encoder.get_attention_mask / get_rel_embedding,
+    DisentangledSelfAttention.forward / disentangled_attention_bias."""
+    eps = geo.layer_norm_eps
+    H, dh, T = geo.heads, geo.head_dim, input_ids.shape[0]
+    span = geo.position_buckets
+    m = attention_mask.to(torch.float32)
+    h = _ln(sd["embeddings.word_embeddings.weight"][input_ids], sd, "embeddings.LayerNorm", eps) * m[:, None]
+    rel_emb = _ln(sd["encoder.rel_embeddings.weight"][: 2 * span], sd, "encoder.LayerNorm", eps)
+    idx = torch.arange(T)
+    bucket = deberta_log_bucket(idx[:, None] - idx[None, :], span, geo.max_positions)      # [q, k], q - k
+    c2p_idx = torch.clamp(bucket + span, 0, 2 * span - 1)                                   # [q, k]
+    p2c_idx = torch.clamp(-bucket + span, 0, 2 * span - 1)                                  # indexed [k(row), q(col)] below
+    allowed = (attention_mask[:, None] * attention_mask[None, :]).bool()
+    scale = math.sqrt(dh * 3.0)
+    states = [h]
+    for i in range(geo.num_layers):
+        p = f"encoder.layer.{i}"
+        a = p + ".attention.self"
+        wq, bq, wk, bk = sd[a + ".query_proj.weight"], sd[a + ".query_proj.bias"], sd[a + ".key_proj.weight"], sd[a + ".key_proj.bias"]
+        q = _heads(F.linear(h, wq, bq), H)
+        k = _heads(F.linear(h, wk, bk), H)
+        v = _heads(F.linear(h, sd[a + ".value_proj.weight"], sd[a + ".value_proj.bias"]), H)
+        pos_q = _heads(F.linear(rel_emb, wq, bq), H)                  # [H, 2 span, dh]
+        pos_k = _heads(F.linear(rel_emb, wk, bk), H)
+        scores = torch.matmul(q, k.transpose(1, 2) / scale)
+        c2p = torch.matmul(q, pos_k.transpose(1, 2))                  # [H, T, 2 span]
+        scores = scores + torch.gather(c2p, 2, c2p_idx[None].expand(H, T, T)) / scale
+        p2c = torch.matmul(k, pos_q.transpose(1, 2))                  # [H, T(key), 2 span]
+        scores = scores + torch.gather(p2c, 2, p2c_idx[None].expand(H, T, T)).transpose(1, 2) / scale
+        scores = scores.masked_fill(~allowed[None], torch.finfo(torch.float32).min)
+        ctx = torch.matmul(torch.softmax(scores, dim=-1), v).permute(1, 0, 2).reshape(T, H * dh)
+        h = _ln(h + F.linear(ctx, sd[p + ".attention.output.dense.weight"], sd[p + ".attention.output.dense.bias"]),
+                sd, p + ".attention.output.LayerNorm", eps)
+        f = F.linear(F.gelu(F.linear(h, sd[p + ".intermediate.dense.weight"], sd[p + ".intermediate.dense.bias"])),
+                     sd[p + ".output.dense.weight"], sd[p + ".output.dense.bias"])
+        h = _ln(h + f, sd, p + ".output.LayerNorm", eps)
+        states.append(h)
+    return states
+
+
 # ----------------------------------------------------------------------- a19/a20
 def select_state(states: Sequence[Tensor], layer_index: int, use_average: bool) -> Tensor:
     """``--use_average y`` -> mean of the last four states, else states[index]
