@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 8
+#define SER_ABI_VERSION 9
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -185,6 +185,25 @@ int ser_logmel_whisper(const float* wav, const int64_t* sample_offs, int B, cons
  * (feeds the Whisper stem convs, HF modeling_whisper.py:618-619). */
 int ser_pack_act(const float* x, int B, int C, int T, int halo, void* out, int64_t ldo,
                  int64_t out_plane_stride, int mode, void* stream);
+
+/* DeBERTa-v2/v3 variant of the text side (preprocessing/preprocess_deroberta.py:106-107 builds it with AutoModel).
+ * ser_embed_ln_masked: LayerNorm(word_emb[id]) with rows t >= key_lens[b] zeroed (HF modeling_deberta_v2.py
+ * DebertaV2Embeddings in the v3 configuration: no absolute positions, no token types, embeddings * mask).
+ * ser_deberta_attention: softmax((Qc Kc^T + c2p + p2c) / sqrt(3 dh)) V per (sequence, head)
+ * (DisentangledSelfAttention.forward / disentangled_attention_bias).  c2p, p2c: [B*T, ldp] fp32, head h in columns
+ * h*Nr .. h*Nr+Nr-1 = content queries / keys times the position keys / queries (shared q/k projections of the
+ * LayerNorm-ed relative embeddings) restricted to the Nr relative-position rows a T-token sequence reaches;
+ * c2p_col / p2c_col: [2T-1] int32, column inside that window for signed distance d at index d + T - 1
+ * (c2p reads c2p[q][c2p_col[q-k]], p2c reads p2c[k][p2c_col[k-q]]; the log-bucket map is built by the host).
+ * A (query, key) pair counts only if both are real tokens (t < key_lens[b]); a padded query row comes out as the
+ * uniform average of all T value rows, as HF's masked_fill(finfo.min) + softmax gives.  T <= 128, dh <= 64. */
+int ser_embed_ln_masked(const int32_t* ids, const float* word_emb, const float* ln_g, const float* ln_b, float eps,
+                        const int32_t* key_lens, float* out_f32, void* out_act, int64_t out_plane_stride,
+                        int mode, int B, int T, int D, void* stream);
+int ser_deberta_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
+                          const float* c2p, const float* p2c, int64_t ldp, int Nr, const int32_t* c2p_col,
+                          const int32_t* p2c_col, const int32_t* key_lens, void* out, int64_t ldo,
+                          int64_t out_plane_stride, int B, int T, int H, int dh, int mode, void* stream);
 
 /* K15 mean of 4 fp32 states (--use_average y; preprocess_speech.py:52-63). */
 int ser_mean4(const float* s0, const float* s1, const float* s2, const float* s3, float* out,

@@ -1,0 +1,169 @@
+// DeBERTa-v2/v3 text variant (next row 8f-1, preprocessing/preprocess_deroberta.py): the two pieces its encoder needs
+// beyond the shared GEMM / LayerNorm kernels.  Sequences are 80 tokens in the reference (max_len), so these are
+// small-problem kernels: clarity over throughput.
+//
+//   ser_embed_ln_masked   LayerNorm(word_embedding[id]) with padded rows zeroed
+//                         (HF modeling_deberta_v2.py DebertaV2Embeddings: no absolute positions / token types in v3)
+//   ser_deberta_attention disentangled attention (DisentangledSelfAttention.forward + disentangled_attention_bias):
+//                         softmax((Qc Kc^T + c2p + p2c) / sqrt(3 dh)) V with the "both tokens real" mask
+#include "ser_common.h"
+
+// ---------------------------------------------------------------------------------------------- embeddings
+template <int MODE>
+__global__ __launch_bounds__(256) void embed_ln_masked_kernel(const int32_t* __restrict__ ids, const float* __restrict__ wemb,
+                                                              const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                              const int32_t* __restrict__ key_lens, float* __restrict__ of,
+                                                              unsigned short* __restrict__ oa, int64_t plane, int T, int D,
+                                                              int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);                 // one wave per token
+    if (row >= rows) return;
+    const int seq = row / T, t = row - seq * T;
+    const bool real = t < key_lens[seq];
+    const float* w = wemb + (int64_t)ids[row] * D;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            v[i] = *(const f32x4*)(w + c);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(b + c);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = real ? (v[i][j] - mean) * rstd * gg[j] + bb[j] : 0.f;   // embeddings * mask
+            if (of) *(f32x4*)(of + (int64_t)row * D + c) = y;
+            if (oa) store_act4<MODE>(oa + (int64_t)row * D + c, plane, y[0], y[1], y[2], y[3]);
+        }
+    }
+}
+
+extern "C" int ser_embed_ln_masked(const int32_t* ids, const float* word_emb, const float* ln_g, const float* ln_b, float eps,
+                                   const int32_t* key_lens, float* out_f32, void* out_act, int64_t out_plane_stride,
+                                   int mode, int B, int T, int D, void* stream) {
+    if (!ids || !word_emb || !ln_g || !ln_b || !key_lens || (!out_f32 && !out_act))
+        return ser_fail(-1, "ser_embed_ln_masked: null pointer");
+    if (B <= 0 || T <= 0 || D % 4 || D > 2048) return ser_fail(-2, "ser_embed_ln_masked: bad B/T/D");
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_embed_ln_masked: bad mode");
+    const int rows = B * T;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(embed_ln_masked_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, ids, word_emb, ln_g, ln_b,
+                           eps, key_lens, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, rows);
+    else
+        hipLaunchKernelGGL(embed_ln_masked_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, ids, word_emb, ln_g, ln_b,
+                           eps, key_lens, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, rows);
+    return ser_check_launch("ser_embed_ln_masked");
+}
+
+// ---------------------------------------------------------------------------------------------- attention
+// One block per (sequence, head), one thread per query (T <= 128, dh <= 64).  K and V of the head sit in LDS as fp32,
+// the score row of every query in LDS too; two passes (scores + max, then exp / sum / P V).
+//   score(q,k) = (Qc_q . Kc_k + c2p[q][ci[q-k]] + p2c[k][pi[k-q]]) * scale        if q and k are real tokens
+//              = lowest float                                                       otherwise
+// so a padded query row is the uniform average of all T value rows, exactly as HF's masked_fill + softmax.
+// c2p / p2c: [rows, H * Nr] fp32 = Qc / Kc times the (shared-projection) position keys / queries restricted to the
+// Nr relative-position rows a T-token sequence can reach; ci / pi: [2T-1] column of that window per signed distance.
+template <int MODE>
+__global__ __launch_bounds__(128) void deberta_attention_kernel(
+    const unsigned short* __restrict__ qkv, int64_t ld, int64_t plane, int q_col, int k_col, int v_col,
+    const float* __restrict__ c2p, const float* __restrict__ p2c, int64_t ldp, int Nr,
+    const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ key_lens,
+    unsigned short* __restrict__ out, int64_t ldo, int64_t out_plane, int T, int H, int dh, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = (float*)smem;                       // [T][dh]
+    float* Vs = Ks + T * dh;                        // [T][dh]
+    float* Ss = Vs + T * dh;                        // [T][T + 1]
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)b * T;
+    const int len = key_lens[b];
+    auto act = [&](int64_t r, int col) -> float {   // one element of a bf16 (+ lo plane) operand
+        const unsigned short* p = qkv + r * ld + col;
+        float x = bf2f(p[0]);
+        if (MODE == SER_MODE_FP32X) x += bf2f(p[plane]);
+        return x;
+    };
+    for (int i = tid; i < T * dh; i += 128) {
+        const int k = i / dh, d = i - k * dh;
+        Ks[i] = act(row0 + k, k_col + h * dh + d);
+        Vs[i] = act(row0 + k, v_col + h * dh + d);
+    }
+    __syncthreads();
+    const int q = tid;
+    if (q >= T) return;
+    float qv[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) qv[d] = d < dh ? act(row0 + q, q_col + h * dh + d) : 0.f;
+    const float* c2p_row = c2p + (row0 + q) * ldp + (int64_t)h * Nr;
+    float* srow = Ss + q * (T + 1);
+    const float lowest = -3.402823466e+38f;
+    const bool qreal = q < len;
+    float m = lowest;
+    for (int k = 0; k < T; ++k) {
+        float s = lowest;
+        if (qreal && k < len) {
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) dot = fmaf(qv[d], d < dh ? Ks[k * dh + d] : 0.f, dot);
+            const float bias = c2p_row[ci[q - k + T - 1]] + p2c[(row0 + k) * ldp + (int64_t)h * Nr + pi[k - q + T - 1]];
+            s = (dot + bias) * scale;
+        }
+        srow[k] = s;
+        m = fmaxf(m, s);
+    }
+    float l = 0.f;
+    float o[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) o[d] = 0.f;
+    for (int k = 0; k < T; ++k) {
+        const float e = __expf(srow[k] - m);                            // all-lowest row: exp(0) = 1 for every key -> uniform
+        l += e;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) o[d] = fmaf(e, d < dh ? Vs[k * dh + d] : 0.f, o[d]);
+    }
+    const float inv = 1.0f / l;
+    unsigned short* orow = out + (row0 + q) * ldo + h * dh;
+    for (int d = 0; d < dh; d += 4)
+        store_act4<MODE>(orow + d, out_plane, o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+}
+
+extern "C" int ser_deberta_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
+                                     const float* c2p, const float* p2c, int64_t ldp, int Nr, const int32_t* c2p_col,
+                                     const int32_t* p2c_col, const int32_t* key_lens, void* out, int64_t ldo,
+                                     int64_t out_plane_stride, int B, int T, int H, int dh, int mode, void* stream) {
+    if (!qkv || !c2p || !p2c || !c2p_col || !p2c_col || !key_lens || !out) return ser_fail(-1, "ser_deberta_attention: null pointer");
+    if (B <= 0 || H <= 0 || T <= 0 || T > 128) return ser_fail(-2, "ser_deberta_attention: T=%d must be in 1..128", T);
+    if (dh % 4 || dh < 4 || dh > 64) return ser_fail(-3, "ser_deberta_attention: head dim %d unsupported (multiple of 4, <= 64)", dh);
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-4, "ser_deberta_attention: bad mode %d", mode);
+    if (Nr <= 0 || ldp < (int64_t)H * Nr || (ldo % 4)) return ser_fail(-5, "ser_deberta_attention: bad position-table pitch");
+    const size_t lds = (size_t)(2 * T * dh + T * (T + 1)) * 4;
+    const float scale = 1.0f / sqrtf(3.0f * (float)dh);
+    auto k = mode == SER_MODE_FP32X ? deberta_attention_kernel<SER_MODE_FP32X> : deberta_attention_kernel<SER_MODE_BF16>;
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ser_fail((int)e, "ser_deberta_attention: cannot raise dynamic LDS");
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(128), lds, (hipStream_t)stream, (const unsigned short*)qkv, ld, plane_stride,
+                       q_col, k_col, v_col, c2p, p2c, ldp, Nr, c2p_col, p2c_col, key_lens, (unsigned short*)out, ldo,
+                       out_plane_stride, T, H, dh, scale);
+    return ser_check_launch("ser_deberta_attention");
+}

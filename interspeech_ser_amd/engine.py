@@ -18,6 +18,7 @@ exist, so no attention / conv masking is needed) and waste no FLOPs on padding.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -946,6 +947,150 @@ class TextEncoder(_EncoderBase):
         return HiddenStates(states, pl["frame_offs_host"])
 
 
+def _deberta_log_bucket(rel: torch.Tensor, bucket_size: int, max_position: int) -> torch.Tensor:
+    """Signed distance -> bucket, in the float32 arithmetic HF uses (modeling_deberta_v2.py make_log_bucket_position):
+    identity inside +-bucket_size/2, logarithmic beyond.  O(T) host work per sequence length; the kernels only see the
+    resulting integer columns."""
+    mid = bucket_size // 2
+    sign = torch.sign(rel)
+    inside = (rel < mid) & (rel > -mid)
+    a = torch.where(inside, torch.full_like(rel, mid - 1), rel.abs()).to(torch.float32)
+    logp = torch.ceil(torch.log(a / mid) / math.log((max_position - 1) / mid) * (mid - 1)) + mid
+    return torch.where(a <= mid, rel.to(torch.float32), logp * sign).to(torch.long)
+
+
+class DebertaEncoder(_EncoderBase):
+    """DeBERTa-v2/v3 text encoder (preprocessing/preprocess_deroberta.py builds it with AutoModel) in its v3
+    configuration: LayerNorm-ed word embeddings (no absolute positions / token types), L post-LayerNorm blocks with
+    disentangled attention.  The relative-position side is input independent, so it is folded at load: LayerNorm of the
+    relative embeddings and their projection through every layer's (shared) query / key weights.  Per layer the device
+    then runs the packed QKV GEMM, two grouped GEMMs (content queries x position keys, content keys x position queries,
+    restricted to the relative rows a T-token sequence can reach), ``ser_deberta_attention``, and the same post-LN
+    output / feed-forward GEMMs as the RoBERTa encoder.  Same call surface as ``TextEncoder``."""
+
+    def __init__(self, geo: EncoderGeometry, state_dict, device="cuda:0", mode: str = "bf16"):
+        super().__init__(geo, device, mode)
+        if geo.family != "deberta":
+            raise ValueError("DebertaEncoder needs a deberta geometry")
+        if geo.head_dim != 64:
+            raise ValueError("DeBERTa path: head dim must be 64 (K of the position GEMMs; deberta-v3 base/large have 64)")
+        sd = state_dict
+        D, span = geo.hidden, geo.position_buckets
+        self.wemb = self._dev_f32(sd["embeddings.word_embeddings.weight"])
+        self.emb_ln = self._ln_pair(sd, "embeddings.LayerNorm")
+        rel = sd["encoder.rel_embeddings.weight"][: 2 * span].double()
+        rel = torch.nn.functional.layer_norm(rel, (D,), sd["encoder.LayerNorm.weight"].double(), sd["encoder.LayerNorm.bias"].double(),
+                                             geo.layer_norm_eps)
+        self.layers = []
+        for i in range(geo.num_layers):
+            p = f"encoder.layer.{i}"
+            a = p + ".attention.self"
+            wq, wk = sd[a + ".query_proj.weight"].double(), sd[a + ".key_proj.weight"].double()
+            bq, bk = sd[a + ".query_proj.bias"].double(), sd[a + ".key_proj.bias"].double()
+            qkv_w = torch.cat([sd[a + ".query_proj.weight"], sd[a + ".key_proj.weight"], sd[a + ".value_proj.weight"]], 0)
+            qkv_b = torch.cat([sd[a + ".query_proj.bias"], sd[a + ".key_proj.bias"], sd[a + ".value_proj.bias"]], 0)
+            self.layers.append(dict(
+                qkv=self._linear(qkv_w, qkv_b),
+                pos_q=(rel @ wq.T + bq).float(), pos_k=(rel @ wk.T + bk).float(),       # [2 span, D] fp32, host: windows cut per T
+                out=self._linear(sd[p + ".attention.output.dense.weight"], sd[p + ".attention.output.dense.bias"]),
+                ln1=self._ln_pair(sd, p + ".attention.output.LayerNorm"),
+                fc1=self._linear(sd[p + ".intermediate.dense.weight"], sd[p + ".intermediate.dense.bias"]),
+                fc2=self._linear(sd[p + ".output.dense.weight"], sd[p + ".output.dense.bias"]),
+                ln2=self._ln_pair(sd, p + ".output.LayerNorm")))
+        self._windows: Dict[int, dict] = {}
+
+    def _window(self, T: int):
+        """Everything that depends on the sequence length only: which relative rows are reachable, the column of every
+        signed distance inside that window, and each layer's position keys / queries cut to it as [H, Nr, dh] GEMM weights."""
+        if T in self._windows:
+            return self._windows[T]
+        geo = self.geo
+        span, H, dh = geo.position_buckets, geo.heads, geo.head_dim
+        d = torch.arange(-(T - 1), T)
+        bucket = _deberta_log_bucket(d, span, geo.max_positions)
+        c2p_row = torch.clamp(bucket + span, 0, 2 * span - 1)            # row of pos_k for distance d = q - k
+        p2c_row = torch.clamp(-bucket + span, 0, 2 * span - 1)           # row of pos_q for distance d = k - q
+        lo = int(min(c2p_row.min(), p2c_row.min()))
+        hi = int(max(c2p_row.max(), p2c_row.max())) + 1
+        Nr = min(2 * span, (hi - lo + 7) // 8 * 8)                       # GEMM N: a multiple of 8 (2 span is one)
+        lo = max(0, min(lo, 2 * span - Nr))                              # ... so slide the window back inside the table
+        w = dict(Nr=Nr, lo=lo,
+                 c2p_col=(c2p_row - lo).to(torch.int32).to(self.device), p2c_col=(p2c_row - lo).to(torch.int32).to(self.device), layers=[])
+        for lay in self.layers:
+            cut = lambda m: m[lo:lo + Nr].reshape(Nr, H, dh).permute(1, 0, 2).reshape(H * Nr, dh)     # noqa: E731
+            w["layers"].append((self._linear(cut(lay["pos_k"]), None), self._linear(cut(lay["pos_q"]), None)))
+        self._windows[T] = w
+        return w
+
+    def _plan(self, B: int, T: int, slot: int = 0):
+        key = (slot, B, T)
+        if key in self._cache:
+            return self._cache[key]
+        geo, dev = self.geo, self.device
+        D, Fd, M = geo.hidden, geo.ffn, B * T
+        win = self._window(T)
+        pl = dict(B=B, T=T, M=M, win=win)
+        pl["frame_offs_host"] = [b * T for b in range(B + 1)]
+        pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
+        pl["xa"], pl["ha"] = self._new_act(M, D), self._new_act(M, D)
+        pl["qkv"], pl["ctx"], pl["ffn"] = self._new_act(M, 3 * D), self._new_act(M, D), self._new_act(M, Fd)
+        pl["c2p"] = torch.empty((M, geo.heads * win["Nr"]), dtype=torch.float32, device=dev)
+        pl["p2c"] = torch.empty((M, geo.heads * win["Nr"]), dtype=torch.float32, device=dev)
+        pl["tmp"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
+        if len(self._cache) >= 4:
+            self._cache.pop(next(iter(self._cache)))
+        self._cache[key] = pl
+        return pl
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, slot: int = 0) -> HiddenStates:
+        """``model(input_ids, attention_mask, output_hidden_states=True).hidden_states`` (preprocess_deroberta.py:57,68)."""
+        B, T = input_ids.shape
+        if attention_mask.shape != input_ids.shape:
+            raise ValueError("attention_mask must have the shape of input_ids")
+        if T > 128:
+            raise ValueError("DeBERTa path: at most 128 tokens per sequence (the reference uses max_len = 80)")
+        mask = attention_mask.to(torch.int64).cpu()
+        klen = mask.sum(dim=1)
+        if not torch.equal(mask, (torch.arange(T)[None, :] < klen[:, None]).to(torch.int64)) or int(klen.min()) < 1:
+            raise ValueError("attention_mask must be right-padded with at least one valid token per sequence")
+        ids = input_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        return self.forward_device(ids, klen.to(device=self.device, dtype=torch.int32), slot)
+
+    @_on_stream
+    def forward_device(self, ids: torch.Tensor, key_lens: torch.Tensor, slot: int = 0) -> HiddenStates:
+        geo = self.geo
+        B, T = ids.shape
+        pl = self._plan(B, T, slot)
+        M, D, H, dh = pl["M"], geo.hidden, geo.heads, geo.head_dim
+        win = pl["win"]
+        Nr = win["Nr"]
+        states, xa, qkv = pl["states"], pl["xa"], pl["qkv"]
+        st = self._s()
+        check(lib.ser_embed_ln_masked(ids.data_ptr(), self.wemb.data_ptr(), self.emb_ln[0].data_ptr(), self.emb_ln[1].data_ptr(),
+                                      float(geo.layer_norm_eps), key_lens.data_ptr(), states[0].data_ptr(), xa.ptr, xa.plane_stride,
+                                      self.mode, B, T, D, st), "ser_embed_ln_masked")
+        for i, lay in enumerate(self.layers):
+            x = states[i]
+            pos_k, pos_q = win["layers"][i]
+            self._gemm(xa, lay["qkv"], M, out_act=qkv)
+            # content -> position and position -> content terms: one grouped GEMM each (group = head, K = dh)
+            self._gemm(qkv, pos_k, M, groups=H, a_group_stride=dh, w_group_stride=Nr * dh, c_group_stride=Nr, N=Nr, K=dh,
+                       out_f32=pl["c2p"], ldo_f32=H * Nr)
+            self._gemm(qkv, pos_q, M, groups=H, a_group_stride=dh, w_group_stride=Nr * dh, c_group_stride=Nr, N=Nr, K=dh,
+                       a_ptr_offset=2 * D, out_f32=pl["p2c"], ldo_f32=H * Nr)
+            check(lib.ser_deberta_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, pl["c2p"].data_ptr(),
+                                            pl["p2c"].data_ptr(), H * Nr, Nr, win["c2p_col"].data_ptr(), win["p2c_col"].data_ptr(),
+                                            key_lens.data_ptr(), pl["ctx"].ptr, pl["ctx"].cols, pl["ctx"].plane_stride,
+                                            B, T, H, dh, self.mode, st), "ser_deberta_attention")
+            self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["tmp"], ldo_f32=D)
+            self._layernorm(pl["tmp"], D, lay["ln1"], M, D, out_f32=pl["h"], out_act=pl["ha"])
+            self._gemm(pl["ha"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
+            self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=pl["tmp"], ldo_f32=D)
+            self._layernorm(pl["tmp"], D, lay["ln2"], M, D, out_f32=states[i + 1], out_act=xa)
+        return HiddenStates(states, pl["frame_offs_host"])
+
+
 def mean_last4(hs: HiddenStates) -> torch.Tensor:
     """``--use_average y``: mean of the last four states (preprocess_speech.py:52-63), on the GPU."""
     s = hs.states
@@ -958,8 +1103,7 @@ def mean_last4(hs: HiddenStates) -> torch.Tensor:
 
 def build_encoder(geo: EncoderGeometry, state_dict, device="cuda:0", mode="bf16"):
     if geo.family == "deberta":
-        raise NotImplementedError("DeBERTa: only the CPU oracle and its fixture exist so far (oracle/ssl_oracle.py); "
-                                  "the HIP path needs a per-(batch, head) 2-D bias mode in ser_attention")
+        return DebertaEncoder(geo, state_dict, device, mode)
     if geo.family == FAMILY_ROBERTA:
         return TextEncoder(geo, state_dict, device, mode)
     if geo.family == FAMILY_WHISPER:

@@ -164,6 +164,38 @@ def test_roberta_golden(golden_dir, mode):
     assert worst < TOL[mode], worst
 
 
+@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+def test_deberta_golden(golden_dir, mode):
+    """DeBERTa-v3 variant of the text side: disentangled attention (log-bucketed relative positions live at 80 tokens with
+    16 buckets), both-token mask, padded query rows, vs the HF DebertaV2Model fixture; plus batch-of-one == batched."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import build_encoder
+    from interspeech_ser_amd.weights import synthetic_state_dict, state_dict_digest
+    geo = C.TINY_DEBERTA
+    gold = np.load(os.path.join(golden_dir, "tiny_deberta_d128h2.npz"))
+    sd = synthetic_state_dict(geo, int(gold["seed"]))
+    assert state_dict_digest(sd) == str(gold["digest"])
+    ids = torch.from_numpy(np.stack([gold[f"ids_{j}"] for j in range(3)]))
+    mask = torch.from_numpy(np.stack([gold[f"mask_{j}"] for j in range(3)]))
+    enc = build_encoder(geo, sd, "cuda:0", mode=mode)
+    hs = enc.forward(ids, mask)
+    torch.cuda.synchronize()
+    assert len(hs) == geo.num_layers + 1
+    worst = 0.0
+    batched = []
+    for j in range(3):
+        ref = torch.from_numpy(gold[f"states_{j}"])
+        assert hs.frames(j) == 80
+        batched.append(hs.utterance(j, geo.num_layers).cpu().clone())
+        for layer in range(ref.shape[0]):
+            worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
+    print(f"deberta {mode}: worst rel err {worst:.3e}")
+    assert worst < TOL[mode], worst
+    one = enc.forward(ids[1:2], mask[1:2])
+    torch.cuda.synchronize()
+    assert torch.equal(one.utterance(0, geo.num_layers).cpu(), batched[1])
+
+
 def test_roberta_driver_files(tmp_path, capsys):
     """preprocess_roberta.py counterpart end to end with a stand-in tokenizer (vocab files are not available offline)."""
     import pandas as pd
