@@ -89,9 +89,9 @@ def cpu_baseline(geo, sd, num_samples, n_clips=6):
 
 def bench_text(args, geo, rank, world, device, D):
     """Next row 8f-1: RoBERTa text extraction, `--batch` texts of `--max_len` tokens per step (synthetic ids)."""
-    from interspeech_ser_amd.engine import TextEncoder
+    from interspeech_ser_amd.engine import build_encoder
     sd, bcast_s = broadcast_weights(geo, 0, rank)
-    enc = TextEncoder(geo, sd, device, args.mode)
+    enc = build_encoder(geo, sd, device, args.mode)
     T = args.max_len
     g = torch.Generator().manual_seed(99 + rank)
     lens = torch.randint(8, T + 1, (args.batch,), generator=g)
@@ -162,7 +162,7 @@ def main():
     if args.layers:
         geo = C.with_layers(geo, args.layers)
     whisper = geo.family == C.FAMILY_WHISPER
-    if geo.family == C.FAMILY_ROBERTA:
+    if geo.family in (C.FAMILY_ROBERTA, C.FAMILY_DEBERTA):
         return bench_text(args, geo, rank, world, device, D)
     num_samples = int(round(args.seconds * 16000))
 

@@ -100,7 +100,18 @@ WHISPER_LARGE_V3 = EncoderGeometry(
 ROBERTA_LARGE = EncoderGeometry(
     family=FAMILY_ROBERTA, num_layers=24, hidden=1024, heads=16, ffn=4096, name="roberta-large")
 
+# deberta-v3: DebertaV2Config(position_buckets=256, share_att_key, pos_att_type p2c|c2p, norm_rel_ebd layer_norm,
+# position_biased_input False, type_vocab_size 0, layer_norm_eps 1e-7, pad_token_id 0, vocab 128100)
+DEBERTA_V3_LARGE = EncoderGeometry(
+    family=FAMILY_DEBERTA, num_layers=24, hidden=1024, heads=16, ffn=4096, vocab_size=128100, max_positions=512,
+    pad_token_id=0, type_vocab_size=0, layer_norm_eps=1e-7, position_buckets=256, name="microsoft/deberta-v3-large")
+DEBERTA_V3_BASE = EncoderGeometry(
+    family=FAMILY_DEBERTA, num_layers=12, hidden=768, heads=12, ffn=3072, vocab_size=128100, max_positions=512,
+    pad_token_id=0, type_vocab_size=0, layer_norm_eps=1e-7, position_buckets=256, name="microsoft/deberta-v3-base")
+
 _REGISTRY = {
+    "microsoft/deberta-v3-large": DEBERTA_V3_LARGE,
+    "microsoft/deberta-v3-base": DEBERTA_V3_BASE,
     "roberta-large": ROBERTA_LARGE,
     "FacebookAI/roberta-large": ROBERTA_LARGE,
     "microsoft/wavlm-large": WAVLM_LARGE,

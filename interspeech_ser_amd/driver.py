@@ -386,8 +386,8 @@ class TextExtractor:
     [n, max_len]; the default uses HF's RobertaTokenizer when its files are available locally."""
 
     def __init__(self, geo, state_dict, device: str, mode: str, tokenize, average: bool):
-        from .engine import TextEncoder
-        self.enc = TextEncoder(geo, state_dict, device, mode)
+        from .engine import build_encoder
+        self.enc = build_encoder(geo, state_dict, device, mode)      # RoBERTa (TextEncoder) or DeBERTa-v3 (DebertaEncoder)
         self.tokenize, self.average = tokenize, average
 
     def extract(self, texts: Sequence[str]) -> List[torch.Tensor]:
@@ -399,10 +399,14 @@ class TextExtractor:
         return [host[hs.frame_offs[b]: hs.frame_offs[b + 1]] for b in range(len(texts))]
 
 
-def hf_tokenize_fn(name_or_path: str, max_len: int):
-    """The reference's tokenizer call (preprocess_roberta.py:48-54); raises OSError without local files."""
-    from transformers import RobertaTokenizer
-    tok = RobertaTokenizer.from_pretrained(name_or_path, local_files_only=True)
+def hf_tokenize_fn(name_or_path: str, max_len: int, family: str = C.FAMILY_ROBERTA):
+    """The reference's tokenizer call (preprocess_roberta.py:48-54, preprocess_deroberta.py:48-54 with
+    DebertaV2Tokenizer); raises OSError without local files."""
+    if family == C.FAMILY_DEBERTA:
+        from transformers.models.deberta_v2 import DebertaV2Tokenizer as Tok
+    else:
+        from transformers import RobertaTokenizer as Tok
+    tok = Tok.from_pretrained(name_or_path, local_files_only=True)
 
     def fn(texts):
         enc = tok(texts, padding="max_length", truncation=True, max_length=max_len, return_tensors="pt")
@@ -410,7 +414,7 @@ def hf_tokenize_fn(name_or_path: str, max_len: int):
     return fn
 
 
-def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None) -> int:
+def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None, family: str = C.FAMILY_ROBERTA) -> int:
     import pandas as pd
     from . import dist as D
     args = build_text_parser().parse_args(argv)
@@ -437,10 +441,10 @@ def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None) -> int:
     D.init(device=torch.device("cuda", local_rank))
     try:
         geo = C.geometry_for(args.roberta_type)
-        if geo.family != C.FAMILY_ROBERTA:
-            raise OSError(f"{args.roberta_type} is not a RoBERTa encoder")
+        if geo.family != family:
+            raise OSError(f"{args.roberta_type} is not a {family} encoder")
         if tokenize is None:
-            tokenize = hf_tokenize_fn(args.tokenizer_path or args.roberta_type, args.max_len)
+            tokenize = hf_tokenize_fn(args.tokenizer_path or args.roberta_type, args.max_len, family)
         sd = None
         if rank == 0:
             sd, src = find_weights(args.roberta_type, args.checkpoint, args.synthetic_weights, args.seed, geo)
@@ -471,6 +475,11 @@ def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None) -> int:
     bar.close()
     D.shutdown()
     return 0
+
+
+def run_deberta(argv: Optional[Sequence[str]] = None, tokenize=None) -> int:
+    """preprocessing/preprocess_deroberta.py: the RoBERTa driver with a DeBERTa-v2/v3 checkpoint and tokenizer."""
+    return run_roberta(argv, tokenize, family=C.FAMILY_DEBERTA)
 
 
 def run_speech(argv: Optional[Sequence[str]] = None) -> int:

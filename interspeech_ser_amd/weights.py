@@ -153,7 +153,7 @@ def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
     return sd
 
 
-_STRIP_PREFIXES = ("wavlm.", "wav2vec2.", "hubert.", "model.", "roberta.")
+_STRIP_PREFIXES = ("wavlm.", "wav2vec2.", "hubert.", "model.", "roberta.", "deberta.")
 
 
 def normalize_names(sd: StateDict) -> StateDict:

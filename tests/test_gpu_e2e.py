@@ -233,6 +233,48 @@ def test_roberta_driver_files(tmp_path, capsys):
     assert rel_err(got, ref) < 1e-3
 
 
+def test_deberta_driver_files(tmp_path, capsys):
+    """preprocess_deroberta.py counterpart end to end at the full deberta-v3-large geometry (160 reachable relative rows
+    at 80 tokens), stand-in tokenizer, against the oracle."""
+    import pandas as pd
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    df = pd.DataFrame({"FileName": ["a_0001.wav", "b_0002.wav"],
+                       "transcription": ["hello there", "a much longer sentence with several more words in it"]})
+    csv = tmp_path / "t.csv"
+    df.to_csv(csv, index=False)
+    max_len = 80
+
+    def fake_tokenize(texts):
+        ids = torch.zeros((len(texts), max_len), dtype=torch.int64)              # pad id 0
+        mask = torch.zeros((len(texts), max_len), dtype=torch.int64)
+        for i, t in enumerate(texts):
+            toks = [1] + [3 + (hash(w) % 100000) for w in t.split()][: max_len - 2] + [2]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return ids, mask
+
+    out = tmp_path / "feats"
+    rc = driver.run_deberta(["--roberta_type", "microsoft/deberta-v3-large", "--df_path", str(csv), "--save_path", str(out),
+                             "--synthetic_weights", "--max_len", "80"], tokenize=fake_tokenize)
+    assert rc == 0, capsys.readouterr().out
+    assert sorted(os.listdir(out)) == ["a_0001.pt", "b_0002.pt"]
+    got = torch.load(out / "b_0002.pt")
+    assert tuple(got.shape) == (80, 1024) and got.dtype == torch.float32
+    geo = C.DEBERTA_V3_LARGE
+    sd = synthetic_state_dict(geo, 7)
+    ids, mask = fake_tokenize(["a much longer sentence with several more words in it"])
+    with torch.no_grad():
+        ref = O.deberta_hidden_states(geo, sd, ids[0], mask[0])[-1]
+    assert rel_err(got, ref) < 1e-3
+    # a RoBERTa name through the DeBERTa driver is refused like an unknown model
+    rc = driver.run_deberta(["--roberta_type", "roberta-large", "--df_path", str(csv), "--save_path", str(out), "--synthetic_weights"],
+                            tokenize=fake_tokenize)
+    assert rc == 0 and "No pretrained model found" in capsys.readouterr().out
+
+
 def test_mean_last4_matches_reference_rule():
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import SpeechEncoder, mean_last4
