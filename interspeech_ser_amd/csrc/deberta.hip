@@ -89,9 +89,9 @@ __global__ __launch_bounds__(128) void deberta_attention_kernel(
     const int32_t* __restrict__ ci, const int32_t* __restrict__ pi, const int32_t* __restrict__ key_lens,
     unsigned short* __restrict__ out, int64_t ldo, int64_t out_plane, int T, int H, int dh, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Ks = (float*)smem;                       // [T][dh]
-    float* Vs = Ks + T * dh;                        // [T][dh]
-    float* Ss = Vs + T * dh;                        // [T][T + 1]
+    float* Ks = (float*)smem;                       // [T][64]
+    float* Vs = Ks + T * 64;                        // [T][64]
+    float* Ss = Vs + T * 64;                        // [T][T + 1]
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)b * T;
@@ -102,17 +102,25 @@ __global__ __launch_bounds__(128) void deberta_attention_kernel(
         if (MODE == SER_MODE_FP32X) x += bf2f(p[plane]);
         return x;
     };
-    for (int i = tid; i < T * dh; i += 128) {
-        const int k = i / dh, d = i - k * dh;
-        Ks[i] = act(row0 + k, k_col + h * dh + d);
-        Vs[i] = act(row0 + k, v_col + h * dh + d);
+    for (int i = tid; i < T * 64; i += 128) {
+        const int k = i >> 6, d = i & 63;
+        Ks[i] = d < dh ? act(row0 + k, k_col + h * dh + d) : 0.f;
+        Vs[i] = d < dh ? act(row0 + k, v_col + h * dh + d) : 0.f;
     }
     __syncthreads();
     const int q = tid;
     if (q >= T) return;
-    float qv[64];
+    // head dims below 64 are zero-padded in LDS / registers (dh % 4 == 0), so every inner loop is 16 aligned float4 steps
+    f32x4 qv[16];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) qv[d] = d < dh ? act(row0 + q, q_col + h * dh + d) : 0.f;
+    for (int d4 = 0; d4 < 16; ++d4) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (4 * d4 < dh) {
+            t[0] = act(row0 + q, q_col + h * dh + 4 * d4); t[1] = act(row0 + q, q_col + h * dh + 4 * d4 + 1);
+            t[2] = act(row0 + q, q_col + h * dh + 4 * d4 + 2); t[3] = act(row0 + q, q_col + h * dh + 4 * d4 + 3);
+        }
+        qv[d4] = t;
+    }
     const float* c2p_row = c2p + (row0 + q) * ldp + (int64_t)h * Nr;
     float* srow = Ss + q * (T + 1);
     const float lowest = -3.402823466e+38f;
@@ -121,9 +129,11 @@ __global__ __launch_bounds__(128) void deberta_attention_kernel(
     for (int k = 0; k < T; ++k) {
         float s = lowest;
         if (qreal && k < len) {
-            float dot = 0.f;
+            const f32x4* kr = (const f32x4*)(Ks + k * 64);
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < 64; ++d) dot = fmaf(qv[d], d < dh ? Ks[k * dh + d] : 0.f, dot);
+            for (int d4 = 0; d4 < 16; ++d4) acc4 = __builtin_elementwise_fma(qv[d4], kr[d4], acc4);
+            const float dot = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             const float bias = c2p_row[ci[q - k + T - 1]] + p2c[(row0 + k) * ldp + (int64_t)h * Nr + pi[k - q + T - 1]];
             s = (dot + bias) * scale;
         }
@@ -131,19 +141,23 @@ __global__ __launch_bounds__(128) void deberta_attention_kernel(
         m = fmaxf(m, s);
     }
     float l = 0.f;
-    float o[64];
+    f32x4 o[16];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) o[d] = 0.f;
+    for (int d4 = 0; d4 < 16; ++d4) o[d4] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < T; ++k) {
         const float e = __expf(srow[k] - m);                            // all-lowest row: exp(0) = 1 for every key -> uniform
         l += e;
+        const f32x4* vr = (const f32x4*)(Vs + k * 64);
+        const f32x4 e4 = {e, e, e, e};
 #pragma unroll
-        for (int d = 0; d < 64; ++d) o[d] = fmaf(e, d < dh ? Vs[k * dh + d] : 0.f, o[d]);
+        for (int d4 = 0; d4 < 16; ++d4) o[d4] = __builtin_elementwise_fma(e4, vr[d4], o[d4]);
     }
     const float inv = 1.0f / l;
     unsigned short* orow = out + (row0 + q) * ldo + h * dh;
-    for (int d = 0; d < dh; d += 4)
-        store_act4<MODE>(orow + d, out_plane, o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+#pragma unroll
+    for (int d4 = 0; d4 < 16; ++d4)
+        if (4 * d4 < dh)
+            store_act4<MODE>(orow + 4 * d4, out_plane, o[d4][0] * inv, o[d4][1] * inv, o[d4][2] * inv, o[d4][3] * inv);
 }
 
 extern "C" int ser_deberta_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
@@ -155,7 +169,7 @@ extern "C" int ser_deberta_attention(const void* qkv, int64_t ld, int64_t plane_
     if (dh % 4 || dh < 4 || dh > 64) return ser_fail(-3, "ser_deberta_attention: head dim %d unsupported (multiple of 4, <= 64)", dh);
     if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-4, "ser_deberta_attention: bad mode %d", mode);
     if (Nr <= 0 || ldp < (int64_t)H * Nr || (ldo % 4)) return ser_fail(-5, "ser_deberta_attention: bad position-table pitch");
-    const size_t lds = (size_t)(2 * T * dh + T * (T + 1)) * 4;
+    const size_t lds = (size_t)(2 * T * 64 + T * (T + 1)) * 4;
     const float scale = 1.0f / sqrtf(3.0f * (float)dh);
     auto k = mode == SER_MODE_FP32X ? deberta_attention_kernel<SER_MODE_FP32X> : deberta_attention_kernel<SER_MODE_BF16>;
     if (lds > 65536) {
