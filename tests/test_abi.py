@@ -85,3 +85,22 @@ def test_command_list_reports_the_failing_entry(built_library):
     assert _lib.lib.ser_run(cmds, 1, ctypes.byref(failed), None) < 0
     assert b"unknown op" in _lib.lib.ser_last_error()
     assert _lib.lib.ser_run(cmds, 0, None, None) == 0
+
+
+def test_deberta_launchers_validate_arguments(built_library):
+    from interspeech_ser_amd import _lib
+    assert _lib.lib.ser_embed_ln_masked(None, None, None, None, 1e-7, None, None, None, 0, 1, 1, 8, 64, None) < 0
+    assert b"ser_embed_ln_masked" in _lib.lib.ser_last_error()
+    assert _lib.lib.ser_deberta_attention(None, 0, 0, 0, 0, 0, None, None, 0, 0, None, None, None, None, 0, 0, 1, 8, 1, 64, 1, None) < 0
+    assert b"ser_deberta_attention" in _lib.lib.ser_last_error()
+
+
+def test_deberta_bucket_map_of_the_host_equals_the_oracle(built_library):
+    """The product's host-side log-bucket map (engine) and the oracle's are written separately; they must agree on every
+    distance a 128-token sequence can produce, for the v3 setting (256 buckets, 512 positions) and the fixture's."""
+    import torch
+    from interspeech_ser_amd.engine import _deberta_log_bucket
+    from oracle import ssl_oracle as O
+    d = torch.arange(-511, 512)
+    for buckets, maxpos in ((256, 512), (16, 512), (32, 128)):
+        assert torch.equal(_deberta_log_bucket(d, buckets, maxpos), O.deberta_log_bucket(d, buckets, maxpos))
