@@ -96,3 +96,40 @@ def test_whisper_driver_crop(tmp_path, capsys):
     assert tuple(a.shape) == (50, 1280)                                # ceil(16000/320)
     assert tuple(b.shape) == (1280, 1280)                              # capped by the hidden size (reference quirk)
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
+
+
+def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
+    """BASELINE.json configs[4] in miniature: HuBERT-xlarge speech features + RoBERTa-large text features for the same
+    utterances, written by the two drivers, read back the way the bimodal head's dataset / collate / forward do."""
+    import pandas as pd
+    from interspeech_ser_amd import driver
+    from test_consumer_contract import _Head, _collate, _item
+    wav_dir, d1, d2 = tmp_path / "Audios", tmp_path / "hubert", tmp_path / "roberta"
+    wav_dir.mkdir()
+    names = [f"MSP_{i:03d}.wav" for i in range(4)]
+    for i, n in enumerate(names):
+        write_wav(wav_dir / n, synth(30 + i, 16000 * (1 + i % 3) + 123 * i))
+    df = pd.DataFrame({"FileName": names, "transcription": ["yes", "no not really", "what a lovely day it is today", "hm"]})
+    csv = tmp_path / "labels.csv"
+    df.to_csv(csv, index=False)
+
+    def tok(texts, max_len=80):
+        ids = torch.full((len(texts), max_len), 1, dtype=torch.int64)
+        mask = torch.zeros((len(texts), max_len), dtype=torch.int64)
+        for i, t in enumerate(texts):
+            toks = [0] + [3 + (hash(w) % 40000) for w in t.split()] + [2]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return ids, mask
+
+    assert driver.run_speech(["--ssl_type", "facebook/hubert-xlarge-ll60k", "--wav_dir", str(wav_dir), "--save_path", str(d1),
+                              "--synthetic_weights", "--mode", "bf16", "--n_layer", "-1", "--batch_size", "3"]) == 0
+    assert driver.run_roberta(["--roberta_type", "roberta-large", "--df_path", str(csv), "--save_path", str(d2),
+                               "--synthetic_weights", "--mode", "bf16"], tokenize=tok) == 0
+    assert sorted(os.listdir(d1)) == sorted(os.listdir(d2)) == [n.replace(".wav", ".pt") for n in names]
+    labels = np.eye(8, dtype=np.float32)[[0, 3, 5, 7]]
+    batch = _collate([_item(n, str(d1), str(d2), lab) for n, lab in zip(names, labels)])
+    assert batch["feat1"].shape[0] == 4 and batch["feat1"].shape[2] == 1280 and batch["feat2"].shape == (4, 80, 1024)
+    with torch.no_grad():
+        logits = _Head(1280, 1024).eval()(batch["feat1"], batch["feat2"])
+    assert logits.shape == (4, 8) and torch.isfinite(logits).all()
