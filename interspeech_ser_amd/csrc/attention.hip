@@ -96,6 +96,7 @@ void attention_kernel(const AttnParams p) {
     const int hh = lane >> 5, l31 = lane & 31;
     const int TK = p.key_lens ? p.key_lens[b] : T;               // attendable keys (== T for speech)
     const int nkt = (TK + ABKV - 1) / ABKV;
+    const int jmin = max(0, (T - 1) - (q0 + 32 * NWV - 1));         // first relative-position slot any query of this block reads
 
     // ---- staging helpers: thread owns chunks c = tid + i*256 of the [64 keys][CPR] tile --------
     u32x4 stg[NP][2][NCH];
@@ -175,8 +176,9 @@ void attention_kernel(const AttnParams p) {
     if (TBL) {
         // each table element is read ONCE (5 independent loads in flight per thread and pass) and
         // scattered into the 4 shifted copies; indices past 2T-1 are written as zeros (tail padding)
-        const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T);
-        const int n = 2 * T - 1, span = p.bias_stride + 3;
+        // only the distances this block's queries can see: key - query + T-1 in [jmin, jmin + 32*NWV + T + 63]
+        const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T) + jmin;
+        const int n = 2 * T - 1 - jmin, span = p.bias_stride + 3;
         for (int base = 0; base < span; base += 5 * NT) {
             float v[5];
 #pragma unroll
@@ -206,9 +208,9 @@ void attention_kernel(const AttnParams p) {
             gq2 = (ga * (gb * g_c - 1.f) + 2.f) * LOG2E;
         }
     }
-    // aligned bias window: index of key kb (multiple of 4) is kb - qc + T-1 = a + sh with a % 4 == 0
-    const int bsh = (T - 1 - qc) & 3;
-    const float* bcopy = ldsB + bsh * p.bias_stride + ((T - 1 - qc) - bsh);
+    // aligned bias window: index of key kb (multiple of 4) is kb - qc + T-1 - jmin = a + sh with a % 4 == 0
+    const int bsh = (T - 1 - qc - jmin) & 3;
+    const float* bcopy = ldsB + bsh * p.bias_stride + ((T - 1 - qc - jmin) - bsh);
 
     f32x16 ot[DSUB];
 #pragma unroll
@@ -457,7 +459,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     // lane group then land on 16 distinct 4-bank slots (a multiple of 64 made them 2-way conflicts)
     int bias_stride = 0;
     if (table) {
-        bias_stride = ((2 * max_frames + ABKV + 3) / 4) * 4;
+        bias_stride = ((max_frames + 32 * nwv + 2 * ABKV + 3) / 4) * 4;       // window of one query block, not all 2T-1 distances
         bias_stride += (16 - (bias_stride & 63) + 64) & 63;
     }
     const size_t lds = (size_t)nbuf * 2 * np * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
