@@ -10,9 +10,15 @@ over one batch of 16 synthetic 10 s clips already resident in HBM (BASELINE.json
 Utterances shard across ranks with no data-path collective (weak scaling): the only RCCL
 traffic is the one-time broadcast of the frozen weights from rank 0.
 
-One JSON line on rank 0: metric/value/unit + `roofline` (dominant kernel = the MFMA GEMM,
-live HIP-event timing inside the timed region) + `cpu_baseline` (CPU oracle, reference-style
-batch-of-one driver, bounded sample, rank 0 at N=1 only).
+A counted step replays `--reps` such batches back to back (default 8, stated in `config`), so that the timed
+region of the default run lasts > 1 s and a GPU-busy sampler can see it; `value` counts every utterance.
+
+One JSON line on rank 0: metric/value/unit + `roofline` (dominant kernel = the MFMA GEMM, live HIP-event
+timing) + `verified` / `verification` (the outputs of the very graph that was timed, checked after the timed
+region: bit-equal to the eager command-list path, within the bf16 bound of an fp32x run, and that fp32x run within
+1e-3 of the CPU oracle) + `parity_mode` (throughput and measured error of the mode that passes north_star's 1e-3)
++ `end_to_end` (wav files on tmpfs -> decode -> H2D -> forward -> D2H -> .pt files through the driver)
++ `cpu_baseline` (CPU oracle, reference-style batch-of-one driver, bounded sample, rank 0 at N=1 only).
 """
 import argparse
 import json
@@ -66,7 +72,7 @@ def broadcast_weights(geo, seed, rank):
     return sd, dt
 
 
-def cpu_baseline(geo, sd, num_samples, n_clips=6):
+def cpu_baseline(geo, sd, num_samples, n_clips=8):
     """The CPU oracle driven like the reference: batch of one, ThreadPoolExecutor(4)
     (preprocess_speech.py:120-122), default torch intra-op threads."""
     from concurrent.futures import ThreadPoolExecutor
@@ -125,19 +131,99 @@ def bench_text(args, geo, rank, world, device, D):
     D.shutdown()
 
 
+def kernel_source_digest():
+    """sha256 over the kernel sources: a PMC summary under profiles/ is only quoted when it was taken from these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "interspeech_ser_amd", "csrc")
+    files = sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.join(ROOT, "include", "ser_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def rel_err(got, ref):
+    """max|a-b| / max(1, max|b|): the tolerance form of tests/test_gpu_e2e.py."""
+    return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+def states_err(hs_a, ua, hs_b, ub):
+    """worst rel_err over all L+1 states of utterance ua of hs_a against utterance ub of hs_b (same length)."""
+    return max(rel_err(hs_a.utterance(ua, l).float(), hs_b.utterance(ub, l).float()) for l in range(len(hs_a)))
+
+
+def oracle_states(geo, sd, wave, whisper):
+    from oracle import ssl_oracle as O                    # checker only
+    with torch.no_grad():
+        if whisper:
+            return O.whisper_hidden_states(geo, sd, torch.from_numpy(O.whisper_log_mel(wave, geo.n_mels)))
+        return O.speech_hidden_states(geo, sd, torch.from_numpy(O.zero_mean_unit_var(wave)))
+
+
+def end_to_end_leg(args, enc, geo, whisper, n_files, num_samples):
+    """SURVEY 8d timing (ii): wav files on tmpfs -> decode -> pinned H2D -> forward -> selection -> D2H -> .pt on tmpfs,
+    through the product's own driver (preprocess_speech.py:47-71 per file), re-using the encoder that was just timed."""
+    import shutil
+    import tempfile
+    import wave as wavmod
+    import numpy as np
+    from interspeech_ser_amd import driver
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    root = tempfile.mkdtemp(prefix="ser_e2e_", dir=base)
+    try:
+        wav_dir, out = os.path.join(root, "wav"), os.path.join(root, "pt")
+        os.makedirs(wav_dir)
+        rng = np.random.default_rng(4321)
+        for i in range(n_files):
+            pcm = (np.clip(0.1 * rng.standard_normal(num_samples), -1, 1) * 32767).astype("<i2")
+            with wavmod.open(os.path.join(wav_dir, f"syn_{i:05d}.wav"), "wb") as wf:
+                wf.setnchannels(1)
+                wf.setsampwidth(2)
+                wf.setframerate(16000)
+                wf.writeframes(pcm.tobytes())
+        argv = ["--ssl_type", args.ssl_type, "--wav_dir", wav_dir, "--save_path", out, "--mode", args.mode,
+                "--batch_size", str(args.batch), "--num_workers", str(args.e2e_workers)]
+        factory = lambda a, w, d: driver._Extractor.from_encoder(a, enc, w)          # noqa: E731
+        import contextlib
+        import io
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(io.StringIO()):
+            (driver.run_whisper if whisper else driver.run_speech)(argv, extractor_factory=factory)
+        last = getattr(driver._run, "last", None)
+        written = len(os.listdir(out)) if os.path.isdir(out) else 0
+        if not last or written != n_files:
+            return {"error": f"driver wrote {written} of {n_files} files", "log_tail": sink.getvalue()[-400:]}
+        t = last["launch_thread"]
+        return {"value": round(last["done"] / last["wall_s"], 1), "unit": "utterances/s", "files": n_files,
+                "wall_s": round(last["wall_s"], 3), "batch_size": args.batch, "host_threads": args.e2e_workers,
+                "launch_thread_s": {k: round(v, 3) for k, v in t.items()},
+                "what": "wav (PCM16, tmpfs) -> decode -> pinned H2D -> forward -> selected state -> D2H -> .pt (tmpfs), "
+                        "one process, driver of preprocessing/preprocess_speech.py; weights already resident"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=8, help="batches replayed back to back per counted step")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--max_len", type=int, default=80, help="tokens per text (roberta workloads)")
     ap.add_argument("--ssl_type", type=str, default="microsoft/wavlm-large")
-    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x"])
+    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x", "f16"])
+    ap.add_argument("--parity-mode", type=str, default="fp32x", help="numerics mode of the parity_mode record")
     ap.add_argument("--layers", type=int, default=0, help="debug: truncate the encoder (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip per-launch GEMM events")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output checks of the timed path")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity_mode record (second encoder + oracle)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (files on tmpfs) leg")
+    ap.add_argument("--e2e-files", type=int, default=256)
+    ap.add_argument("--e2e-workers", type=int, default=4, help="host threads of the end-to-end leg (reference default 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--split", type=str, default="", help="explicit utterance-group sizes, e.g. 9,7 (overrides --micro)")
     ap.add_argument("--micro", type=int, default=2,
@@ -165,6 +251,7 @@ def main():
     if geo.family in (C.FAMILY_ROBERTA, C.FAMILY_DEBERTA):
         return bench_text(args, geo, rank, world, device, D)
     num_samples = int(round(args.seconds * 16000))
+    reps = max(1, args.reps)
 
     sd, bcast_s = broadcast_weights(geo, 0, rank)
     enc = build_encoder(geo, sd, device, args.mode)
@@ -183,31 +270,61 @@ def main():
         assert sum(sizes) == args.batch and min(sizes) > 0, "--split must add up to --batch"
         micro, cuts = len(sizes), [sum(sizes[:i]) for i in range(len(sizes) + 1)]
         per = max(sizes)
-    groups = [(enc.upload(waves[a:b]), lengths[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    spans = list(zip(cuts[:-1], cuts[1:]))
+
+    def make_groups(e):
+        return [(e.upload(waves[a:b], slot=slot), lengths[a:b]) for slot, (a, b) in enumerate(spans)]
+
+    groups = make_groups(enc)
     torch.cuda.synchronize()
 
-    def eager_step():
-        for slot, (w, l) in enumerate(groups):
-            enc.forward(w, l, slot=slot)
+    def eager_step(e=enc, grp=groups):
+        return [e.forward(w, l, slot=slot) for slot, (w, l) in enumerate(grp)]
 
-    if args.no_graph:
-        step = eager_step
-    else:
-        graph, hs = enc.capture_concurrent(groups)
-        step = graph.replay
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(e, grp):
+        """(elapsed seconds of `steps` counted steps, the HiddenStates the replayed graph writes into)"""
+        if args.no_graph:
+            hs_ref = [None]
+
+            def one():
+                hs_ref[0] = eager_step(e, grp)
+            hs = None
+        else:
+            graph, hs = e.capture_concurrent(grp)
+            one = graph.replay
+        for _ in range(args.warmup):
+            for _ in range(reps):
+                one()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for _ in range(reps):
+                one()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        return dt, (hs if hs is not None else hs_ref[0])
+
+    elapsed, hs_timed = timed(enc, groups)
+
+    # ---- verification of what was just timed (rank 0): the states the LAST replay left in HBM
+    verification = None
+    if rank == 0 and not args.no_verify:
+        kept = [h.states.clone() for h in hs_timed]
+        eager = eager_step()                                      # same arenas, command-list path, default stream
+        torch.cuda.synchronize()
+        same = all(torch.equal(k, e.states) for k, e in zip(kept, eager)) and \
+            all(k_h.frame_offs == e.frame_offs for k_h, e in zip(hs_timed, eager))
+        finite = all(bool(torch.isfinite(k).all()) for k in kept)
+        verification = {"graph_replay_equals_eager_bitwise": bool(same), "all_finite": finite,
+                        "states_checked": int(sum(k.shape[0] for k in kept)), "utterances": args.batch}
+        from interspeech_ser_amd.engine import HiddenStates
+        hs_timed = [HiddenStates(k, h.frame_offs) for k, h in zip(kept, hs_timed)]    # the timed graph's own results, kept
+        del eager
 
     # Roofline leg: the same K steps again, launched eagerly with a HIP event pair around every
     # ser_gemm launch on the launch stream (events cannot be timed inside a replayed graph).
@@ -237,18 +354,21 @@ def main():
     elapsed = D.max_over_ranks(elapsed)
 
     if rank == 0:
-        total_utts = args.batch * args.steps * world
+        total_utts = args.batch * reps * args.steps * world
         value = total_utts / elapsed
         gf_utt = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
+        dtype_name = {"bf16": "bf16", "fp32x": "bf16x3 (fp32-grade split)", "f16": "f16 (fp32x stem)"}
         out = {
             "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract" if geo is C.WAVLM_LARGE and abs(args.seconds - 10) < 1e-6
                       else f"utterances/sec ({args.seconds:.0f} s @16 kHz) {geo.name} embed extract",
             "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.mode == "bf16" else "bf16x3 (fp32-grade split)", "data": "synthetic",
+            "dtype": dtype_name[args.mode], "data": "synthetic",
             "config": {"workload": f"{geo.name} embed extract, batch={args.batch} x {args.seconds:.0f} s @16 kHz per GPU, "
-                                   f"all {geo.num_layers + 1} hidden states to HBM, mode={args.mode}",
+                                   f"all {geo.num_layers + 1} hidden states to HBM, mode={args.mode}; a counted step = "
+                                   f"{reps} such batches back to back ({args.batch * reps} utterances per GPU)",
+                       "batch": args.batch, "batches_per_step": reps, "ms_per_batch": round(1e3 * elapsed / args.steps / reps, 3),
                        "frames_per_utt": geo.max_source_positions if whisper else geo.frames_for(num_samples), "gflop_per_utt": round(gf_utt, 1),
                        "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
             "achieved_tflops_whole_path": round(value * gf_utt / 1e3 / world, 1),
@@ -259,8 +379,17 @@ def main():
             dur_ms = sum(t[0].elapsed_time(t[1]) for t in trace)
             flops = sum(t[2] for t in trace)
             algo_bytes = sum(t[3] for t in trace)
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"] if os.path.isfile(pmc) else None
+            # HBM bytes per launch: only from a PMC summary taken with THESE kernel sources on THIS workload
+            traffic, traffic_note = None, "no rocprofv3 PMC summary for these kernel sources / this workload under profiles/"
+            key = f"{geo.name}|{args.mode}|batch={args.batch}x{args.seconds:.0f}s|groups={micro}"
+            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if fn.endswith("pmc_traffic.json"):
+                    rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    if rec.get("kernel_source_digest") == kernel_source_digest() and rec.get("workload_key") == key:
+                        traffic = rec["hbm_bytes_per_launch"]
+                        traffic_note = (f"HBM bytes per ser_gemm launch from separate rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, "
+                                        f"profiles/{fn}), same command run eagerly, same kernel sources ({rec['kernel_source_digest']})")
+                        break
             n = len(trace)
             achieved = flops / (dur_ms * 1e-3) / 1e12
             mult = 3.0 if args.mode == "fp32x" else 1.0
@@ -268,14 +397,14 @@ def main():
                 "kernel": "ser_gemm_kernel (bf16 MFMA implicit-conv GEMM + fused epilogue)",
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, "
-                                "profiles/r01_pmc_traffic.json), same command run eagerly",
+                "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": round(algo_bytes / n),
                 "launches": n, "avg_launch_us": round(1e3 * dur_ms / n, 2),
                 "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
                 "mfma_products_per_algorithmic_flop": mult,
-                "gemm_ms_per_step": round(dur_ms / args.steps, 3),
-                "measured": "HIP events around every ser_gemm launch, eager pass of the same K steps right after the timed region",
+                "gemm_ms_per_batch": round(dur_ms / args.steps, 3),
+                "measured": "HIP events around every ser_gemm launch, eager pass of K batches right after the timed region "
+                            "(one launch at a time: no concurrent utterance group)",
             }
         if blocks:
             T = geo.frames_for(num_samples)
@@ -297,8 +426,46 @@ def main():
                 out["attention_block"]["whole_batch_per_launch"] = {
                     "utterances_per_launch": blocks_full[0][2], "us_per_layer_call": round(us_f, 2),
                     "achieved": round(ach_f, 1), "frac": round(ach_f / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+        # ---- parity_mode: throughput + measured errors of the mode that meets north_star's 1e-3 (rank 0, N = 1)
+        checks_ok = verification is not None and verification["graph_replay_equals_eager_bitwise"] and verification["all_finite"]
+        if world == 1 and not args.no_parity and verification is not None:
+            pmode = args.parity_mode
+            first = [a for a, _ in spans]                                 # first utterance of every group
+            if pmode == args.mode:
+                enc_p, hs_p, el_p = enc, hs_timed, elapsed
+            else:
+                enc_p = build_encoder(geo, sd, device, pmode)
+                grp_p = make_groups(enc_p)
+                torch.cuda.synchronize()
+                el_p, hs_p = timed(enc_p, grp_p)
+            err_mode = max(states_err(hs_timed[g], 0, hs_p[g], 0) for g in range(len(spans)))
+            ref = oracle_states(geo, sd, waves[0], whisper)               # CPU oracle on utterance 0 (full geometry, T frames)
+            err_p = max(rel_err(hs_p[0].utterance(0, l).cpu(), r) for l, r in enumerate(ref))
+            err_m = max(rel_err(hs_timed[0].utterance(0, l).cpu(), r) for l, r in enumerate(ref))
+            bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3}[args.mode]
+            out["parity_mode"] = {
+                "mode": pmode, "value": round(args.batch * reps * args.steps / el_p, 2), "unit": "utterances/s",
+                "ms_per_batch": round(1e3 * el_p / args.steps / reps, 3),
+                "max_rel_err_vs_oracle": float(f"{err_p:.3e}"), "tolerance": 1e-3,
+                "oracle_sample": f"utterance 0 ({args.seconds:.0f} s, all {geo.num_layers + 1} states, {ref[0].shape[0]} frames), fp32 PyTorch-CPU oracle",
+                "error_form": "max|a-b| / max(1, max|b|) per hidden state, worst state",
+            }
+            verification.update({
+                "timed_mode": args.mode, "timed_mode_max_rel_err_vs_oracle": float(f"{err_m:.3e}"),
+                "timed_mode_max_rel_err_vs_parity_mode": float(f"{err_mode:.3e}"),
+                "timed_mode_bound": bound, "utterances_vs_parity_mode": first,
+                "parity_mode_within_1e-3_of_oracle": bool(err_p <= 1e-3)})
+            checks_ok = checks_ok and err_p <= 1e-3 and err_m <= bound and err_mode <= bound
+            if enc_p is not enc:
+                del enc_p, hs_p
+                torch.cuda.empty_cache()
+        if verification is not None:
+            out["verified"] = bool(checks_ok)
+            out["verification"] = verification
+        if world == 1 and not args.no_e2e:
+            out["end_to_end"] = end_to_end_leg(args, enc, geo, whisper, args.e2e_files, num_samples)
         if world == 1 and not args.no_cpu_baseline and not whisper:
-            from interspeech_ser_amd.weights import synthetic_state_dict
             out["cpu_baseline"] = cpu_baseline(geo, sd, num_samples)
         print(json.dumps(out), flush=True)
     D.shutdown()

@@ -125,6 +125,15 @@ class _Extractor:
         self.enc = build_encoder(self.geo, sd, device, args.mode)
         self.average = args.use_average == "y"
 
+    @classmethod
+    def from_encoder(cls, args, enc, whisper: bool, weight_source: str = "caller's encoder"):
+        """Wrap an encoder the caller already built (bench.py's end-to-end leg, tests): no weight search, no broadcast."""
+        ex = cls.__new__(cls)
+        ex.args, ex.whisper, ex.geo, ex.enc = args, whisper, enc.geo, enc
+        ex.weight_source, ex.bcast_s, ex.bcast_bytes = weight_source, 0.0, 0
+        ex.average = args.use_average == "y"
+        return ex
+
     def extract(self, waves: List[np.ndarray], layer_index: int) -> List[torch.Tensor]:
         """One ragged batch -> one CPU [T, D] tensor per utterance (rows a19/a20), synchronously."""
         from .engine import mean_last4
@@ -194,7 +203,10 @@ class _Extractor:
         return buf[:rows]
 
 
-def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
+def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -> int:
+    """``extractor_factory(args, whisper, device)`` replaces ``_Extractor`` (bench.py hands in its already-built encoder;
+    the CPU gloo tests hand in a stub so that everything around the model call -- sharding, the compat layer index,
+    disjoint writes, failure reporting -- runs without a GPU)."""
     from . import dist as D
     args = build_parser(whisper).parse_args(argv)
     rank, world, local_rank = D.env()
@@ -220,17 +232,18 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
         for m in missing:
             log(f" - {m}")
         log("Something went wrong, make sure everything is correct before running again!")
+        D.shutdown()
         return 0
 
     log(f"Extracting features using {args.ssl_type}")
-    if device == "cpu":
+    if device == "cpu" and extractor_factory is None:
         # the product has exactly one backend; say so instead of silently computing elsewhere
         print("Error: no MI355X visible -- this build has no CPU path (the CPU oracle under oracle/ is test-only)")
         print("Something went wrong, make sure everything is correct before running again!")
         D.shutdown()
         return 0
     try:
-        ex = _Extractor(args, whisper, device)
+        ex = (extractor_factory or _Extractor)(args, whisper, device)
     except OSError as e:
         log(f"Error: No pretrained model found with the name {args.ssl_type}")
         log(f"  ({e})")
@@ -240,18 +253,23 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
     log(f"Weights: {ex.weight_source}; numerics mode {args.mode}")
 
     num_states = ex.geo.num_layers + 1
-    if whisper:
-        layer_index = None if average else resolve_layer_index(args.n_layer, num_states)
-    elif args.compat_layer_quirk:
+    if average:
+        layer_index = None
+    elif args.compat_layer_quirk and not whisper:
         layer_index = n_existing                         # preprocess_speech.py:41,67 (may be out of range -> per-file failure)
     else:
-        layer_index = None if average else resolve_layer_index(args.n_layer, num_states)
+        # an out-of-range --n_layer is what ``hidden_states[N]`` raises per file in the reference (IndexError inside
+        # the per-file try/except): keep the raw index and let every file report it, instead of crashing here
+        layer_index = args.n_layer if args.n_layer >= 0 else num_states + args.n_layer
+    bad_layer = layer_index is not None and not 0 <= layer_index < num_states
 
+    # Shard the UNFILTERED, deterministic list first; --skip_existing then filters each rank's own shard.  (Filtering
+    # before sharding raced: a fast rank's first .pt files changed the list slower ranks were still about to shard.)
     paths = [os.path.join(args.wav_dir, w) for w in sorted(wav_names)]
-    if args.skip_existing:
-        paths = [p for p in paths if not os.path.isfile(feature_path(args.save_path, p))]
     sizes = [os.path.getsize(p) for p in paths]
     mine = shard_files(paths, sizes, rank, world)
+    if args.skip_existing:
+        mine = [p for p in mine if not os.path.isfile(feature_path(args.save_path, p))]
     batches = make_batches(mine, max(1, args.batch_size))
 
     def decode(path):
@@ -273,7 +291,7 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
     audio_s = 0.0
     bar = tqdm(total=len(mine), desc="Extracting features", disable=(rank != 0))
     from collections import deque
-    pipelined = not whisper
+    pipelined = getattr(ex, "pipelined", not whisper)
     with ThreadPoolExecutor(max_workers=max(1, args.num_workers)) as pool:
         pending = pool.map(decode, batches[0]) if batches else []
         writes = []
@@ -282,7 +300,8 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
         def one_by_one(good):
             """A failed batch is retried per utterance so one bad file cannot drop its neighbours."""
             nonlocal done, audio_s
-            torch.cuda.synchronize()                          # the synchronous path shares slot 0's arena with the pipeline
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()                      # the synchronous path shares slot 0's arena with the pipeline
             for path, wave in good:
                 try:
                     f = ex.extract([wave], layer_index)[0]
@@ -320,10 +339,11 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
                     print(f"Failed to process {path}: {err}")
                 else:
                     good.append((path, wave))
-            if good:
+            if good and bad_layer:
+                for path, _ in good:
+                    print(f"Failed to process {path}: tuple index out of range")
+            elif good:
                 try:
-                    if layer_index is not None and not 0 <= layer_index < num_states:
-                        raise IndexError("tuple index out of range")
                     if pipelined:
                         t_a = clock()
                         ticket = ex.submit([w for _, w in good], layer_index, slot=bi % ex.SLOTS)
@@ -352,7 +372,16 @@ def _run(argv: Optional[Sequence[str]], whisper: bool) -> int:
     bar.close()
     dt = time.perf_counter() - t0
     total_done, wall = D.sum_over_ranks(done), D.max_over_ranks(dt)
+    total_audio = D.sum_over_ranks(audio_s)
     log(f"{int(total_done)} utterances on {world} GPU(s) in {wall:.2f} s ({total_done / max(wall, 1e-9):.1f} utt/s)")
+    # one machine-readable line per run (metrics/logging row)
+    import json
+    log("SER_RUN " + json.dumps({
+        "utterances": int(total_done), "audio_s": round(total_audio, 1), "wall_s": round(wall, 3), "n_gpus": world,
+        "utt_per_s": round(total_done / max(wall, 1e-9), 1), "audio_s_per_s": round(total_audio / max(wall, 1e-9), 1),
+        "mode": args.mode, "ssl_type": args.ssl_type, "batch_size": args.batch_size, "num_workers": args.num_workers,
+        "host_cpus": os.cpu_count()}))
+    _run.last = dict(done=int(total_done), wall_s=wall, audio_s=total_audio, launch_thread=dict(tm))
     if args.timing:
         log("launch thread: " + ", ".join(f"{k} {v:.3f} s" for k, v in tm.items()) + f", total {dt:.3f} s")
         if getattr(ex, "tm", None):
@@ -445,9 +474,16 @@ def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None, family: str
             raise OSError(f"{args.roberta_type} is not a {family} encoder")
         if tokenize is None:
             tokenize = hf_tokenize_fn(args.tokenizer_path or args.roberta_type, args.max_len, family)
-        sd = None
+        sd, err = None, ""
         if rank == 0:
-            sd, src = find_weights(args.roberta_type, args.checkpoint, args.synthetic_weights, args.seed, geo)
+            try:
+                sd, src = find_weights(args.roberta_type, args.checkpoint, args.synthetic_weights, args.seed, geo)
+            except OSError as e:
+                err = str(e)
+        # every rank learns about a failed load BEFORE anybody enters the weight broadcast (the speech driver's rule):
+        # otherwise ranks > 0 sit in broadcast_object_list until the collective times out
+        if D.broadcast_int(1 if (rank == 0 and sd is None) else 0) == 1:
+            raise OSError(err or "rank 0 found no checkpoint")
         sd, _, _ = D.broadcast_state_dict(sd)
         ex = TextExtractor(geo, sd, f"cuda:{local_rank}", args.mode, tokenize, average)
     except OSError as e:
@@ -460,8 +496,9 @@ def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None, family: str
     bar = tqdm(total=len(mine), desc="Extracting features", disable=(rank != 0))
     with ThreadPoolExecutor(max_workers=max(1, args.num_workers)) as pool:
         writes = []
-        for i in range(0, len(mine), max(1, args.batch_size)):
-            idx = mine[i:i + args.batch_size]
+        bs = max(1, args.batch_size)
+        for i in range(0, len(mine), bs):
+            idx = mine[i:i + bs]
             try:
                 feats = ex.extract([texts[j] for j in idx])
                 for j, f in zip(idx, feats):
@@ -482,9 +519,9 @@ def run_deberta(argv: Optional[Sequence[str]] = None, tokenize=None) -> int:
     return run_roberta(argv, tokenize, family=C.FAMILY_DEBERTA)
 
 
-def run_speech(argv: Optional[Sequence[str]] = None) -> int:
-    return _run(argv, whisper=False)
+def run_speech(argv: Optional[Sequence[str]] = None, extractor_factory=None) -> int:
+    return _run(argv, whisper=False, extractor_factory=extractor_factory)
 
 
-def run_whisper(argv: Optional[Sequence[str]] = None) -> int:
-    return _run(argv, whisper=True)
+def run_whisper(argv: Optional[Sequence[str]] = None, extractor_factory=None) -> int:
+    return _run(argv, whisper=True, extractor_factory=extractor_factory)

@@ -1,0 +1,166 @@
+"""BASELINE.json configs[1..3] at FULL geometry, outputs checked (-m gpu).
+
+Round 1 timed these workloads without ever looking at what they produced.  Here each one runs at the batch
+shape the config names and is compared three ways (tolerance form of test_gpu_e2e.py:
+max|a-b| <= tol * max(1, max|b|) per hidden state):
+
+  (a) the exact launch path bench.py times -- hipGraph replay of two concurrent utterance-group branches --
+      is bit-equal to the eager command-list path on the same inputs;
+  (b) every state of >= 2 utterances of the bf16 run lies within the bf16 bound (3e-2) of the fp32x run;
+  (c) the fp32x run lies within north_star's 1e-3 of the CPU oracle (oracle/ssl_oracle.py) on a full-length
+      utterance -- T = 499 frames for the 10 s speech clips, 1500 for Whisper's 30 s window.
+
+Reference call sites: preprocessing/preprocess_speech.py:49-67, preprocessing/preprocess_whisper.py:48-76.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_PARITY = 1e-3
+TOL_BF16 = 3e-2
+
+
+def rel_err(got, ref):
+    return float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+def synth_clips(n, num_samples, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(0.1 * torch.randn(num_samples, generator=g)).numpy() for _ in range(n)]
+
+
+def worst_vs_oracle(hs, b, ref, rows=None):
+    worst = 0.0
+    for layer, r in enumerate(ref):
+        got = hs.utterance(b, layer).cpu()
+        if rows is not None:
+            got, r = got[:rows], r[:rows]
+        assert got.shape == r.shape, (got.shape, r.shape)
+        worst = max(worst, rel_err(got, r))
+    return worst
+
+
+def worst_between(hs_a, hs_b, utts):
+    return max(rel_err(hs_a.utterance(b, l), hs_b.utterance(b, l)) for b in utts for l in range(len(hs_a)))
+
+
+def _speech_config(ssl_type, batch, seed, oracle_utts=(0,)):
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.geometry_for(ssl_type)
+    sd = synthetic_state_dict(geo, 0)
+    num_samples = 160000
+    waves = synth_clips(batch, num_samples, seed)
+    lengths = [num_samples] * batch
+    half = batch // 2
+    spans = [(0, half), (half, batch)]
+
+    def run(mode):
+        enc = SpeechEncoder(geo, sd, "cuda:0", mode=mode)
+        groups = [(enc.upload(waves[a:b], slot=s), lengths[a:b]) for s, (a, b) in enumerate(spans)]
+        torch.cuda.synchronize()
+        graph, hs = enc.capture_concurrent(groups)
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+        kept = [h.states.clone() for h in hs]
+        eager = [enc.forward(w, l, slot=s) for s, (w, l) in enumerate(groups)]
+        torch.cuda.synchronize()
+        for k, e, h in zip(kept, eager, hs):
+            assert e.frame_offs == h.frame_offs
+            assert h.frames(0) == geo.frames_for(num_samples) == 499
+            assert torch.equal(k, e.states), f"{ssl_type} {mode}: hipGraph replay differs from the eager command-list path"
+        return enc, hs, kept
+
+    enc32, hs32, kept32 = run("fp32x")
+    worst32 = 0.0
+    for b in oracle_utts:
+        with torch.no_grad():
+            ref = O.speech_hidden_states(geo, sd, torch.from_numpy(O.zero_mean_unit_var(waves[b])))
+        assert len(ref) == geo.num_layers + 1 and ref[0].shape == (499, geo.hidden)
+        g, u = (0, b) if b < half else (1, b - half)
+        worst32 = max(worst32, worst_vs_oracle(hs32[g], u, ref))
+    state32 = [k.cpu() for k in kept32]
+    offs = [h.frame_offs for h in hs32]
+    del enc32, hs32, kept32
+    torch.cuda.empty_cache()
+    enc16, hs16, kept16 = run("bf16")
+    worst16 = 0.0
+    for g in range(2):
+        a = kept16[g].cpu()
+        for u in (0, len(offs[g]) - 2):                                   # first and last utterance of each group
+            r0, r1 = offs[g][u], offs[g][u + 1]
+            for layer in range(a.shape[0]):
+                worst16 = max(worst16, rel_err(a[layer, r0:r1], state32[g][layer, r0:r1]))
+    print(f"{ssl_type} B={batch} x 10 s: fp32x vs oracle {worst32:.3e}; bf16 vs fp32x (4 utterances, all states) {worst16:.3e}")
+    assert worst32 < TOL_PARITY, worst32
+    assert worst16 < TOL_BF16, worst16
+
+
+def test_config1_wavlm_large_16x10s_timed_path():
+    """configs[1]: WavLM-large, batch = 16 x 10 s, bf16, two-branch hipGraph replay -- the headline workload."""
+    _speech_config("microsoft/wavlm-large", 16, 1234)
+
+
+def test_config2_xlsr_2b_8x10s():
+    """configs[2]: wav2vec2-XLS-R-2B (D = 1920, 48 layers, head dim 120, 120-channel pos-conv groups), batch = 8 x 10 s."""
+    _speech_config("facebook/wav2vec2-xls-r-2b", 8, 1235)
+
+
+def test_config4_hubert_xlarge_16x10s():
+    """The speech half of configs[4]: HuBERT-xlarge (D = 1280, head dim 80), batch = 16 x 10 s."""
+    _speech_config("facebook/hubert-xlarge-ll60k", 16, 1237)
+
+
+def test_config3_whisper_large_v3_16x30s():
+    """configs[3]: Whisper-large-v3 encoder, batch = 16 x 30 s windows, GPU log-mel front end, the reference's crop.
+    Clips of mixed true lengths (each is padded to the 30 s window like WhisperFeatureExtractor does)."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import WhisperEncoder
+    from interspeech_ser_amd.frontend import whisper_saved_rows
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.geometry_for("openai/whisper-large-v3")
+    sd = synthetic_state_dict(geo, 0)
+    secs = [30.0, 7.3, 12.0, 30.0, 3.0, 22.5, 9.9, 30.0, 15.0, 4.2, 28.0, 30.0, 11.1, 6.0, 19.0, 30.0]
+    g = torch.Generator().manual_seed(1236)
+    waves = [(0.1 * torch.randn(int(s * 16000), generator=g)).numpy() for s in secs]
+    lengths = [len(w) for w in waves]
+
+    def run(mode):
+        enc = WhisperEncoder(geo, sd, "cuda:0", mode=mode)
+        packed = enc.upload(waves)
+        mel = enc.log_mel(packed, lengths).clone()
+        hs = enc.forward(packed, lengths)
+        torch.cuda.synchronize()
+        return enc, mel, hs
+
+    enc32, mel32, hs32 = run("fp32x")
+    assert len(hs32) == geo.num_layers + 1 == 33 and hs32.frames(0) == 1500
+    worst32 = worst_mel = 0.0
+    for b in (0, 1):                                                       # a full window and a 7.3 s clip
+        ref_mel = O.whisper_log_mel(waves[b], geo.n_mels)
+        worst_mel = max(worst_mel, float(np.abs(mel32[b].cpu().numpy() - ref_mel).max()))
+        with torch.no_grad():
+            ref = O.whisper_hidden_states(geo, sd, torch.from_numpy(ref_mel))
+        rows = whisper_saved_rows(lengths[b], geo.hidden)                  # preprocess_whisper.py:49-50,75-76
+        assert rows == min(int(np.ceil(lengths[b] / 320)), 1280) == O.whisper_crop_rows(lengths[b], geo.hidden)
+        worst32 = max(worst32, worst_vs_oracle(hs32, b, ref, rows=rows))
+    s32 = hs32.states.cpu()
+    offs = hs32.frame_offs
+    del enc32, hs32
+    torch.cuda.empty_cache()
+    enc16, mel16, hs16 = run("bf16")
+    s16 = hs16.states.cpu()
+    worst16 = 0.0
+    for b in (0, 4, 15):
+        for layer in range(s16.shape[0]):
+            worst16 = max(worst16, rel_err(s16[layer, offs[b]:offs[b + 1]], s32[layer, offs[b]:offs[b + 1]]))
+    print(f"whisper-large-v3 B=16 x 30 s: log-mel abs err {worst_mel:.2e}; fp32x vs oracle {worst32:.3e}; bf16 vs fp32x {worst16:.3e}")
+    assert worst_mel < 1e-3, worst_mel
+    assert worst32 < TOL_PARITY, worst32
+    assert worst16 < TOL_BF16, worst16

@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32x": 1e-3, "bf16": 8e-2}
+TOL = {"fp32x": 1e-3, "bf16": 3e-2}     # bf16: measured 0.6-1.5e-2 on these fixtures (round 1), gate at 2x that
 
 
 def synth_wave(seed, n):
