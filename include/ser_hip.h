@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 9
+#define SER_ABI_VERSION 10
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -127,6 +127,20 @@ typedef struct ser_gemm_args {
      * attention kernel's softmax runs in the exp2 domain with no per-score multiply. */
     float          col_scale;
     int32_t        col_scale_end;  /* multiple of 4; 0 = no scaling */
+    /* SHIFTED operand copy for the deferred LayerNorm.  Real checkpoints carry offsets in the residual stream (rows
+     * whose mean is many standard deviations); rounding such a row to bf16 and then forming acc - mu*colsum loses the
+     * signal.  With shift_out != NULL the launch computes, per row,
+     *   c[m] = shift_const + (shift_in ? shift_in[m] : 0) + (shift_stats ? sum_g shift_stats[m][g][0] / shift_cols : 0)
+     * i.e. the absolute row mean of its RESIDUAL input (whose row partials were written relative to shift_in) plus a
+     * load-time constant (mean of the bias), stores it in shift_out[m], and writes out_act and stat_out for v - c[m]
+     * (out_f32 keeps v).  LayerNorm is shift invariant, so the consuming GEMM is unchanged. */
+    const float*   shift_stats;    /* [M][shift_groups][2] row partials of the residual rows, or NULL */
+    int32_t        shift_groups;   /* even */
+    int32_t        shift_cols;     /* columns of a residual row (divisor of the partial sums) */
+    const float*   shift_in;       /* [M] shift the residual's partials are relative to, or NULL (0) */
+    float*         shift_out;      /* [M] or NULL (no shifting) */
+    float          shift_const;
+    int32_t        reserved1;
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
 

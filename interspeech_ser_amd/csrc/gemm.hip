@@ -192,6 +192,31 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     // deferred LayerNorm: row mean / rstd of the A rows from the producer's partial sums, into the
     // LDS words behind the ring (one row per thread; the loads fly beside the first DMA tiles)
     float* lnst = (float*)(lds + ST * STAGE);                         // [BM][2]
+    float* shf = lnst + 2 * BM;                                       // [BM] shift of the act copy / row partials
+    // SHIFTED operand copy (see ser_hip.h): c[m] = absolute row mean of the residual input (+ a load-time constant).
+    // The act copy and the row partials this launch writes hold v - c[m], so rows whose mean is many standard
+    // deviations (offsets living in the residual stream) still round to bf16 relative to their spread, and the
+    // consumer's E[x^2] - mean^2 does not cancel.  LayerNorm is shift invariant: the consumer needs no change.
+    if (p.shift_out) {
+        for (int r = tid; r < BM; r += NT) {
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            float c = p.shift_const;
+            if (p.shift_in) c += p.shift_in[m];
+            if (p.shift_stats) {
+                const float* ps = p.shift_stats + (int64_t)m * p.shift_groups * 2;
+                float s1 = 0.f;
+                for (int u = 0; u < p.shift_groups; u += 2) {
+                    const f32x4 pv = *(const f32x4*)(ps + 2 * u);
+                    s1 += pv[0] + pv[2];
+                }
+                c += s1 / (float)p.shift_cols;
+            }
+            shf[r] = c;
+            if (nt == 0 && g == 0 && m0 + r < p.M) p.shift_out[m] = c;
+        }
+        if (!p.ln_stats_in) __syncthreads();
+    }
     if (p.ln_stats_in) {
         for (int r = tid; r < BM; r += NT) {
             int m = m0 + r;
@@ -384,6 +409,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 mu = lnst[2 * (wm * TM * 16 + mi * 16 + frow)];
                 rs = lnst[2 * (wm * TM * 16 + mi * 16 + frow) + 1];
             }
+            const float cshift = p.shift_out ? shf[wm * TM * 16 + mi * 16 + frow] : 0.f;
             float st1 = 0.f, st2 = 0.f;
 #pragma unroll
             for (int ni = 0; ni < TN; ni += 2) {                      // fragment column blocks ni, ni+1: 4 + 4 columns
@@ -412,6 +438,16 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
                     v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
                 }
+                if (p.out_f32) {
+                    float* op = p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 16 - p.f32_col_begin;
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    if (ok0 && ncol0 + ni * 16 >= p.f32_col_begin) *(f32x4*)op = o0;
+                    if (ok1 && ncol0 + ni * 16 + 16 >= p.f32_col_begin) *(f32x4*)(op + 16) = o1;
+                }
+                if (p.shift_out) {                                    // wave-uniform; the fp32 output above stays unshifted
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] -= cshift;
+                }
                 if (do_stat && ok0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
@@ -419,12 +455,6 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 if (do_stat && ok1) {
 #pragma unroll
                     for (int r = 4; r < 8; ++r) { st1 += v[r]; st2 += v[r] * v[r]; }
-                }
-                if (p.out_f32) {
-                    float* op = p.out_f32 + (int64_t)m * p.ldo_f32 + gcol + ni * 16 - p.f32_col_begin;
-                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    if (ok0 && ncol0 + ni * 16 >= p.f32_col_begin) *(f32x4*)op = o0;
-                    if (ok1 && ncol0 + ni * 16 + 16 >= p.f32_col_begin) *(f32x4*)(op + 16) = o1;
                 }
                 if (p.out_act) {
                     const int c8 = ni * 16 + ((fq & 1) ? 12 : 0);     // after the swap this lane holds columns c8..c8+7
@@ -454,7 +484,7 @@ template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI>
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const int npl = (a->mode == SER_MODE_FP32X) ? 2 : 1;
-    const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8);   // ring (+ [BM][2] row statistics)
+    const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 12);  // ring (+ [BM][2] row statistics + [BM] row shift)
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     if (a->mode == SER_MODE_BF16) {
@@ -553,6 +583,11 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     }
     if (a->stat_out && (a->ln_gamma || a->stat_groups < a->groups * ((a->N + 63) / 64)))
         return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
+    if (a->shift_out) {
+        if (!a->stat_out || a->ln_gamma) return ser_fail(-19, "ser_gemm: shift_out needs stat_out and no fused-LN epilogue");
+        if (a->shift_stats && (a->shift_groups < 2 || (a->shift_groups & 1) || a->shift_cols <= 0))
+            return ser_fail(-19, "ser_gemm: shift_stats needs an even shift_groups >= 2 and shift_cols > 0");
+    }
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
     if ((a->ldo_act % 8) || (a->c_group_stride % 8)) return ser_fail(-18, "ser_gemm: act pitch / group stride must be multiples of 8");
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");

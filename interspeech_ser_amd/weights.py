@@ -153,6 +153,41 @@ def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
     return sd
 
 
+def apply_stress(sd: StateDict, geo: EncoderGeometry, kind: str) -> StateDict:
+    """Deterministic edits of a synthetic wav2vec2-style state dict that reproduce what real checkpoints do to the
+    residual stream and seeded Gaussian weights never do (fixtures ``tiny_*_outlier`` / ``tiny_*_rowmean``):
+
+    * ``"outliers"``: two "massive activation" channels -- layer 0's feed-forward output writes +800 / -500 into them
+      (1000x the other channels), their weight rows are 30x larger, and every later LayerNorm damps them with a
+      small gamma, as trained models do;
+    * ``"rowmean"``: a uniform offset on every channel (positional-conv bias +40, which passes its GELU unchanged; each
+      feed-forward output bias +3; one attention LayerNorm bias x8), so that rows have |mean| >> std: the one-pass
+      variance and the deferred-LayerNorm term ``acc - mean * colsum`` of csrc/gemm.hip cancel catastrophically
+      unless the operands are stored shifted.
+    """
+    D = geo.hidden
+    sd = {k: v.clone() for k, v in sd.items()}
+    fc2 = "encoder.layers.{}.feed_forward.output_dense"
+    if kind == "outliers":
+        c1, c2 = 7, D - 5
+        sd[fc2.format(0) + ".bias"][c1] += 800.0
+        sd[fc2.format(0) + ".bias"][c2] -= 500.0
+        sd[fc2.format(0) + ".weight"][c1] *= 30.0
+        sd[fc2.format(0) + ".weight"][c2] *= 30.0
+        for k in sd:
+            if k.endswith("layer_norm.weight") and k.startswith("encoder."):
+                sd[k][c1] = 0.05
+                sd[k][c2] = -0.05
+    elif kind == "rowmean":
+        sd["encoder.pos_conv_embed.conv.bias"] += 40.0
+        for i in range(geo.num_layers):
+            sd[fc2.format(i) + ".bias"] += 3.0
+        sd["encoder.layers.0.layer_norm.bias"] *= 8.0
+    else:
+        raise ValueError(f"unknown stress kind '{kind}'")
+    return sd
+
+
 _STRIP_PREFIXES = ("wavlm.", "wav2vec2.", "hubert.", "model.", "roberta.", "deberta.")
 
 

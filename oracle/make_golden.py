@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from interspeech_ser_amd import config as C                     # noqa: E402
-from interspeech_ser_amd.weights import synthetic_state_dict, state_dict_digest  # noqa: E402
+from interspeech_ser_amd.weights import apply_stress, synthetic_state_dict, state_dict_digest  # noqa: E402
 from oracle import ssl_oracle as O                               # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -79,14 +79,20 @@ def load_into(model, sd, allow_missing_prefixes=()):
     assert not res.unexpected_keys, f"unexpected keys: {res.unexpected_keys[:8]}"
 
 
-def speech_case(tag, geo, seed, lengths):
+def speech_case(tag, geo, seed, lengths, stress=None):
+    """``stress``: weights.apply_stress kind -- fixtures whose residual stream carries 1000x outlier channels or rows
+    with |mean| >> std, the two things real checkpoints do and seeded Gaussian weights do not."""
     import transformers as tf
     sd = synthetic_state_dict(geo, seed)
+    if stress:
+        sd = apply_stress(sd, geo, stress)
     model = hf_speech_model(geo)
     load_into(model, sd)
     fe = tf.Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0,
                                      do_normalize=True, return_attention_mask=True)
     rec = {"seed": seed, "digest": state_dict_digest(sd), "lengths": np.array(lengths, dtype=np.int64)}
+    if stress:
+        rec["stress"] = np.array(stress)
     worst = 0.0
     for j, n in enumerate(lengths):
         wave = synth_wave(1000 + 17 * j + seed, n)
@@ -104,7 +110,14 @@ def speech_case(tag, geo, seed, lengths):
         rec[f"wave_seed_{j}"] = np.array(1000 + 17 * j + seed)
         rec[f"states_{j}"] = torch.stack(hs).numpy().astype(np.float32)              # [L+1, T, D]
         rec[f"input_values_{j}"] = ours_in if n <= 20000 else ours_in[:64]
+        if stress:
+            st = torch.stack(hs)
+            rec[f"row_mean_over_std_{j}"] = (st.mean(-1).abs() / st.std(-1)).amax(dim=1).numpy().astype(np.float32)
+            rec[f"absmax_over_median_{j}"] = (st.abs().amax(dim=(1, 2)) / st.abs().flatten(1).median(dim=1).values).numpy().astype(np.float32)
     print(f"{tag}: oracle vs HF rel-max err {worst:.2e}")
+    if stress:
+        print(f"   residual stream: max |row mean|/std per state {rec['row_mean_over_std_0'].round(1).tolist()}, "
+              f"max|x| / median|x| per state {rec['absmax_over_median_0'].round(0).tolist()}")
     assert worst < 2e-5, worst
     np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **rec)
 
@@ -174,7 +187,7 @@ def roberta_case(tag, geo, seed):
 
 
 def deberta_case(tag, geo, seed):
-    """DeBERTa-v3-style fixture (oracle + golden only: the HIP path for disentangled attention is not built yet)."""
+    """DeBERTa-v3-style fixture (HIP counterpart: engine.DebertaEncoder, tests/test_gpu_e2e.py::test_deberta_golden)."""
     import transformers as tf
     sd = synthetic_state_dict(geo, seed)
     cfg = tf.DebertaV2Config(vocab_size=geo.vocab_size, hidden_size=geo.hidden, num_hidden_layers=geo.num_layers,
@@ -261,12 +274,22 @@ def full_size_pins():
         l2=np.array([float(h.norm()) for h in hs], dtype=np.float32))
 
 
+def stress_cases():
+    speech_case("tiny_wavlm_outlier", C.TINY_WAVLM, 21, [16000, 9000], stress="outliers")
+    speech_case("tiny_hubert_outlier", C.TINY_HUBERT, 22, [16000, 9000], stress="outliers")
+    speech_case("tiny_wavlm_rowmean", C.TINY_WAVLM, 23, [16000, 9000], stress="rowmean")
+    speech_case("tiny_hubert_rowmean", C.TINY_HUBERT, 24, [16000, 9000], stress="rowmean")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "deberta":
         deberta_case("tiny_deberta_d128h2", C.TINY_DEBERTA, 17)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stress":        # outlier-stress fixtures only
+        stress_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "roberta":       # add the text fixture without touching the others
         roberta_case("tiny_roberta_d128h2", C.TINY_ROBERTA, 15)
         return
@@ -278,6 +301,7 @@ def main():
     whisper_case("tiny_whisper_d128h2", C.TINY_WHISPER, 14, [16000, 100000])
     roberta_case("tiny_roberta_d128h2", C.TINY_ROBERTA, 15)
     deberta_case("tiny_deberta_d128h2", C.TINY_DEBERTA, 17)
+    stress_cases()
     full_size_pins()
 
 

@@ -58,6 +58,39 @@ def test_speech_golden_ragged_batch(golden_dir, mode, case):
     assert worst < TOL[mode], worst
 
 
+STRESS = [("tiny_wavlm_outlier", "wavlm"), ("tiny_hubert_outlier", "hubert"),
+          ("tiny_wavlm_rowmean", "wavlm"), ("tiny_hubert_rowmean", "hubert")]
+
+
+@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_outlier_stress_fixtures(golden_dir, mode, case):
+    """What real checkpoints do to the residual stream and Gaussian weights do not: two 1000x outlier
+    channels, or rows whose mean is ~45 standard deviations.  HF's fp32 states are the reference.  This is what
+    pins the one-pass row statistics and the deferred-LayerNorm cancellation ``acc - mean * colsum`` of
+    csrc/gemm.hip: producers store the bf16 operand copy SHIFTED by the row mean of their residual input."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import apply_stress, synthetic_state_dict, state_dict_digest
+    tag, fam = STRESS[case]
+    geo = C.TINY_WAVLM if fam == "wavlm" else C.TINY_HUBERT
+    gold = np.load(os.path.join(golden_dir, tag + ".npz"))
+    sd = apply_stress(synthetic_state_dict(geo, int(gold["seed"])), geo, str(gold["stress"]))
+    assert state_dict_digest(sd) == str(gold["digest"])
+    lengths = [int(n) for n in gold["lengths"]]
+    waves = [synth_wave(int(gold[f"wave_seed_{j}"]), n) for j, n in enumerate(lengths)]
+    enc = SpeechEncoder(geo, sd, "cuda:0", mode=mode)
+    hs = enc.forward(enc.upload(waves), lengths)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for j in range(len(lengths)):
+        ref = torch.from_numpy(gold[f"states_{j}"])
+        for layer in range(ref.shape[0]):
+            worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
+    print(f"{tag} {mode}: worst rel err {worst:.3e}")
+    assert worst < TOL[mode], worst
+
+
 def test_batched_equals_single(golden_dir):
     """Packed ragged batch == batch-of-one runs (the reference's B=1 loop), to fp32 rounding."""
     from interspeech_ser_amd import config as C
