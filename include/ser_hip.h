@@ -150,6 +150,13 @@ int ser_layernorm(const float* x, int64_t ldx, const float* g, const float* b, f
                   float* out_f32, int64_t ldo_f32, void* out_act, int64_t ldo_act, int64_t out_plane_stride,
                   int mode, int rows, int D, void* stream);
 
+/* Centred operand copy of hidden_states[0] for the deferred LayerNorm of encoder layer 0 (the LayerNorm itself is
+ * HF modeling_wavlm.py:357): out_act = split(x - mean_row), stats[m][0] = (sum, sum of squares) of the centred row
+ * (remaining slots zero), shift[m] = mean_row.  See ser_gemm_args.shift_out. */
+int ser_row_center(const float* x, int64_t ldx, void* out_act, int64_t ldo_act, int64_t out_plane_stride,
+                   float* stats /*[rows][stat_groups][2]*/, int stat_groups, float* shift /*[rows]*/,
+                   int mode, int rows, int D, void* stream);
+
 /* K8a WavLM relative-position bias as a [H, 2*T-1] table: column (key-query)+(T-1)
  * (compute_bias + _relative_positions_bucket, HF modeling_wavlm.py:243-271). */
 int ser_wavlm_bias_table(const float* rel_attn_embed /*[num_buckets,H]*/, float* table /*[H,2T-1]*/,
@@ -256,6 +263,11 @@ typedef struct ser_layernorm_args {
     int32_t mode, rows, D, reserved0;
 } ser_layernorm_args;
 
+typedef struct ser_row_center_args {
+    const float* x; int64_t ldx; void* out_act; int64_t ldo_act; int64_t out_plane_stride;
+    float* stats; float* shift; int32_t stat_groups, mode, rows, D;
+} ser_row_center_args;
+
 typedef struct ser_wave_frames_args {
     const float* wav; const int64_t* sample_offs; const int32_t* frame_offs; int32_t B, k, stride, mode;
     void* out; int64_t out_plane_stride; void* work; int32_t total_rows, reserved0;
@@ -265,6 +277,7 @@ typedef struct ser_wave_frames_args {
 #define SER_OP_ATTENTION 2
 #define SER_OP_LAYERNORM 3
 #define SER_OP_WAVE_FRAMES 4
+#define SER_OP_ROW_CENTER 5
 typedef struct ser_cmd {
     int32_t op, reserved0;
     union {
@@ -272,6 +285,7 @@ typedef struct ser_cmd {
         ser_attention_args   attention;
         ser_layernorm_args   layernorm;
         ser_wave_frames_args wave_frames;
+        ser_row_center_args  row_center;
     } u;
 } ser_cmd;
 

@@ -21,7 +21,7 @@ ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
 WS_WAVE_FRAMES = 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -43,6 +43,8 @@ class GemmArgs(C.Structure):
         ("ln_stats_in", c_void_p), ("ln_groups", C.c_int32), ("ln_colsum", c_void_p),
         ("stat_out", c_void_p), ("stat_groups", C.c_int32), ("f32_col_begin", C.c_int32),
         ("col_scale", c_float), ("col_scale_end", C.c_int32),
+        ("shift_stats", c_void_p), ("shift_groups", C.c_int32), ("shift_cols", C.c_int32),
+        ("shift_in", c_void_p), ("shift_out", c_void_p), ("shift_const", c_float), ("reserved1", C.c_int32),
     ]
 
 
@@ -79,8 +81,18 @@ class WaveFramesArgs(C.Structure):
     ]
 
 
+class RowCenterArgs(C.Structure):
+    """Mirror of ``ser_row_center_args``."""
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_i64), ("out_act", c_void_p), ("ldo_act", c_i64), ("out_plane_stride", c_i64),
+        ("stats", c_void_p), ("shift", c_void_p),
+        ("stat_groups", C.c_int32), ("mode", C.c_int32), ("rows", C.c_int32), ("D", C.c_int32),
+    ]
+
+
 class _CmdUnion(C.Union):
-    _fields_ = [("gemm", GemmArgs), ("attention", AttentionArgs), ("layernorm", LayerNormArgs), ("wave_frames", WaveFramesArgs)]
+    _fields_ = [("gemm", GemmArgs), ("attention", AttentionArgs), ("layernorm", LayerNormArgs), ("wave_frames", WaveFramesArgs),
+                ("row_center", RowCenterArgs)]
 
 
 class Cmd(C.Structure):
@@ -88,9 +100,9 @@ class Cmd(C.Structure):
     _fields_ = [("op", C.c_int32), ("reserved0", C.c_int32), ("u", _CmdUnion)]
 
 
-OP_GEMM, OP_ATTENTION, OP_LAYERNORM, OP_WAVE_FRAMES = 1, 2, 3, 4
+OP_GEMM, OP_ATTENTION, OP_LAYERNORM, OP_WAVE_FRAMES, OP_ROW_CENTER = 1, 2, 3, 4, 5
 STRUCT_MIRRORS = {"ser_gemm_args": GemmArgs, "ser_attention_args": AttentionArgs, "ser_layernorm_args": LayerNormArgs,
-                  "ser_wave_frames_args": WaveFramesArgs, "ser_cmd": Cmd}
+                  "ser_wave_frames_args": WaveFramesArgs, "ser_row_center_args": RowCenterArgs, "ser_cmd": Cmd}
 
 _SIGNATURES = {
     "ser_version": (c_int, []),
@@ -103,6 +115,7 @@ _SIGNATURES = {
     "ser_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
     "ser_layernorm": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_i64, c_void_p, c_i64,
                               c_i64, c_int, c_int, c_int, c_void_p]),
+    "ser_row_center": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ser_wavlm_bias_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ser_wavlm_gate": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                c_int, c_void_p]),

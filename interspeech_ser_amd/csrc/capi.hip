@@ -68,6 +68,12 @@ extern "C" int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void*
                                      a.work, a.total_rows, stream);
                 break;
             }
+            case SER_OP_ROW_CENTER: {
+                const ser_row_center_args& a = c.u.row_center;
+                rc = ser_row_center(a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride, a.stats, a.stat_groups, a.shift,
+                                    a.mode, a.rows, a.D, stream);
+                break;
+            }
             default:
                 rc = ser_fail(-2, "ser_run: command %d has unknown op %d", i, c.op);
         }

@@ -318,6 +318,64 @@ extern "C" int ser_layernorm(const float* x, int64_t ldx, const float* g, const 
     return ser_check_launch("ser_layernorm");
 }
 
+// ----------------------------------------------------------------- centred operand copy
+// Wave per row: act copy of (x - mean_row), its row partials and the shift, in the layout the deferred-LayerNorm GEMMs
+// consume (ser_gemm_args.ln_stats_in / shift_in).  Run ONCE per forward on hidden_states[0], whose row mean is produced
+// by the launch that writes it (positional conv / Whisper stem) and therefore cannot be known to that launch's tiles;
+// from then on every producer GEMM carries the shift forward from its residual input (ser_hip.h, "SHIFTED operand copy").
+template <int MODE>
+__global__ __launch_bounds__(256) void row_center_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         unsigned short* __restrict__ oa, int64_t ldoa, int64_t plane,
+                                                         float* __restrict__ stats, int stat_groups,
+                                                         float* __restrict__ shift, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) { v[i] = *(const f32x4*)(xr + c); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+        else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            f32x4 d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { d[j] = v[i][j] - mean; q += d[j] * d[j]; r1 += d[j]; }
+            store_act4<MODE>(oa + (int64_t)row * ldoa + c, plane, d[0], d[1], d[2], d[3]);
+        }
+    }
+    q = wave_sum(q);
+    r1 = wave_sum(r1);
+    float* st = stats + (int64_t)row * stat_groups * 2;
+    for (int g2 = lane; g2 < stat_groups * 2; g2 += 64) st[g2] = g2 == 0 ? r1 : (g2 == 1 ? q : 0.f);
+    if (lane == 0) shift[row] = mean;
+}
+
+extern "C" int ser_row_center(const float* x, int64_t ldx, void* out_act, int64_t ldo_act, int64_t out_plane_stride,
+                              float* stats, int stat_groups, float* shift, int mode, int rows, int D, void* stream) {
+    if (!x || !out_act || !stats || !shift) return ser_fail(-1, "ser_row_center: null pointer");
+    if (D % 4 || D > 2048 || D <= 0 || rows <= 0) return ser_fail(-2, "ser_row_center: D=%d rows=%d unsupported", D, rows);
+    if ((ldx % 4) || (ldo_act % 4) || stat_groups < 2 || (stat_groups & 1))
+        return ser_fail(-3, "ser_row_center: pitches must be multiples of 4, stat_groups even and >= 2");
+    dim3 grid((rows + 3) / 4), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(row_center_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
+    else if (mode == SER_MODE_BF16)
+        hipLaunchKernelGGL(row_center_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
+    else return ser_fail(-4, "ser_row_center: bad mode %d", mode);
+    return ser_check_launch("ser_row_center");
+}
+
 // ------------------------------------------------------------------ text embeddings (8f-1)
 // RoBERTa embeddings: word[id] + position[pos] + token_type[0] -> LayerNorm (HF modeling_roberta.py:56-120).
 // Wave per token; position ids = cumsum(non-pad)*non-pad + pad_id, computed per sequence with a wave scan.

@@ -208,7 +208,7 @@ class _EncoderBase:
               residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
               out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0,
               ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0,
-              col_scale=1.0, col_scale_end=0):
+              col_scale=1.0, col_scale_end=0, shift=None):
         rec = self._rec
         g = rec.slot("gemm") if rec is not None else GemmArgs()
         g.A = a.ptr + a_ptr_offset
@@ -243,6 +243,10 @@ class _EncoderBase:
             g.stat_out, g.stat_groups = stat_out.data_ptr(), stat_groups
         g.f32_col_begin = f32_col_begin
         g.col_scale, g.col_scale_end = float(col_scale), int(col_scale_end)
+        if shift is not None:                   # shifted operand copy (ser_hip.h): (residual stats, groups, shift_in, shift_out, const)
+            r_stats, r_groups, s_in, s_out, s_const = shift
+            g.shift_stats, g.shift_groups, g.shift_cols = _ptr(r_stats), int(r_groups), g.N * groups
+            g.shift_in, g.shift_out, g.shift_const = _ptr(s_in), s_out.data_ptr(), float(s_const)
         if rec is not None:
             rec.commit(_lib.OP_GEMM, g, M=M)
             return
@@ -280,6 +284,19 @@ class _EncoderBase:
         check(lib.ser_layernorm(x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu), _ptr(out_f32), ldo_f32,
                                 o_act, ldo_act, ops, self.mode, rows, D, self._s()), "ser_layernorm")
 
+    def _row_center(self, x: torch.Tensor, out_act: Act, stats: torch.Tensor, shift: torch.Tensor, rows: int, D: int):
+        """hidden_states[0] -> centred operand copy + row partials + shift for encoder layer 0 (ser_row_center)."""
+        groups = stats.shape[1]
+        rec = self._rec
+        if rec is not None:
+            a = rec.slot("row_center")
+            a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride = x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride
+            a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.mode, rows, D
+            rec.commit(_lib.OP_ROW_CENTER, a, rows=rows)
+            return
+        check(lib.ser_row_center(x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride, stats.data_ptr(), groups,
+                                 shift.data_ptr(), self.mode, rows, D, self._s()), "ser_row_center")
+
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
                    gru_const=None, key_lens=None):
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
@@ -309,12 +326,15 @@ class _EncoderBase:
     def _run_layers(self, pl, states, first_groups: int, B: int, max_frames: int):
         """Pre-LN / stable-LN encoder layers with BOTH LayerNorms deferred into the consuming GEMMs:
         x -> [QKV(+gate) GEMM: LN1 folded] -> attention -> [out GEMM +x -> h] -> [FC1 GEMM: LN2 folded, GELU]
-          -> [FC2 GEMM +h -> next x].  Producers emit the bf16 operand copy and the row partial sums."""
+          -> [FC2 GEMM +h -> next x].  Producers emit the bf16 operand copy and the row partial sums, both SHIFTED by
+        the row mean of their residual input (carried in sx / sh): offsets that live in the residual stream never
+        reach the bf16 rounding or the one-pass variance.  states[0] is centred once by ser_row_center."""
         geo = self.geo
         M, D, L = pl["M"], geo.hidden, geo.num_layers
         wavlm = geo.family == FAMILY_WAVLM
         gD = self._stat_groups(D)
         gx = first_groups
+        self._row_center(states[0], pl["xa"], pl["px0"], pl["sx"], M, D)
         for i, lay in enumerate(self.layers):
             x = states[i]
             last = i + 1 == L
@@ -331,7 +351,8 @@ class _EncoderBase:
             else:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
             self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D,
-                       out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD)
+                       out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD,
+                       shift=((pl["px0"] if i == 0 else pl["px"]), gx, pl["sx"], pl["sh"], lay["out_bias_mean"]))
             if self.block_trace is not None:
                 b1 = torch.cuda.Event(enable_timing=True)
                 b1.record()
@@ -341,7 +362,8 @@ class _EncoderBase:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
             else:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D,
-                           out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD)
+                           out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD,
+                           shift=(pl["ph"], gD, pl["sh"], pl["sx"], lay["fc2_bias_mean"]))
             gx = gD
         self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
 
@@ -369,6 +391,9 @@ class _EncoderBase:
         lay["out"] = self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"])
         lay["fc1"] = self._linear_ln(sd[fc1 + ".weight"], sd[fc1 + ".bias"], sd[ln2 + ".weight"], sd[ln2 + ".bias"])
         lay["fc2"] = self._linear(sd[fc2 + ".weight"], sd[fc2 + ".bias"])
+        # load-time part of the operand shift: a uniform offset in a bias moves the row mean by exactly its mean
+        lay["out_bias_mean"] = float(sd[a + ".out_proj.bias"].double().mean())
+        lay["fc2_bias_mean"] = float(sd[fc2 + ".bias"].double().mean())
         return lay
 
     def _layer_buffers(self, pl, M: int, first_groups: int):
@@ -380,7 +405,9 @@ class _EncoderBase:
         pl["ha"] = self._new_act(M, D)
         # row partial sums (sum, sum^2 per 64-column group).  One buffer per producer layout: a padding
         # slot (odd group count) is never written and must stay zero.
-        pl["px0"] = torch.zeros((M, first_groups, 2), dtype=torch.float32, device=dev)   # states[0] (stem / pos-conv)
+        pl["px0"] = torch.zeros((M, first_groups, 2), dtype=torch.float32, device=dev)   # states[0] (ser_row_center)
+        pl["sx"] = torch.zeros(M, dtype=torch.float32, device=dev)       # row shift of the xa copy / px partials
+        pl["sh"] = torch.zeros(M, dtype=torch.float32, device=dev)       # row shift of the ha copy / ph partials
         pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
         pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
         pl["qkv"] = self._new_act(M, nqkv)
@@ -531,7 +558,7 @@ class SpeechEncoder(_EncoderBase):
         ar["proj_f32"] = torch.empty((cap["M"], D), dtype=torch.float32, device=dev)
         ar["halo_act"] = self._new_act(cap["halo"], D, zero=True, extra_rows=1)
         ar["states"] = torch.empty((geo.num_layers + 1, cap["M"], D), dtype=torch.float32, device=dev)
-        ar["first_groups"] = self._stat_groups(D // geo.pos_conv_groups, geo.pos_conv_groups)
+        ar["first_groups"] = 2                               # ser_row_center writes one (sum, sum^2) slot + one zero slot
         self._layer_buffers(ar, cap["M"], ar["first_groups"])
         if geo.family == FAMILY_WAVLM:
             ar["table"] = torch.empty(geo.heads * (2 * cap["Tmax"] - 1), dtype=torch.float32, device=dev)
@@ -735,8 +762,7 @@ class SpeechEncoder(_EncoderBase):
         self._gemm(pl["halo_act"], self.pos, M, a_rowoff=pl["pos_rowoff"], kc=kc, ldj=D, groups=G,
                    a_group_stride=Cg, w_group_stride=Cg * geo.pos_conv_kernel * kc, c_group_stride=Cg,
                    N=Cg, K=geo.pos_conv_kernel * kc, act=_lib.ACT_GELU, residual=pl["proj_f32"], ldr=D,
-                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg,
-                   out_act=pl["xa"], stat_out=pl["px0"], stat_groups=pl["first_groups"])
+                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg)
         # a11/a12: stable-LayerNorm encoder layers (LayerNorms deferred into the GEMMs)
         self._run_layers(pl, states, pl["first_groups"], B, pl["Tmax"])
 
@@ -812,7 +838,7 @@ class WhisperEncoder(_EncoderBase):
         pl["frame_offs_host"] = [int(b * T2) for b in range(B + 1)]
         pl["frame_offs"] = torch.tensor(pl["frame_offs_host"], dtype=torch.int32, device=dev)
         pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
-        pl["first_groups"] = self._stat_groups(D)
+        pl["first_groups"] = 2
         self._layer_buffers(pl, M, pl["first_groups"])
         if len(self._cache) >= 3:
             self._cache.pop(next(iter(self._cache)))
@@ -851,8 +877,7 @@ class WhisperEncoder(_EncoderBase):
                    out_rowmap=pl["c1_rowmap"])
         states = pl["states"]
         self._gemm(pl["c1_act"], self.conv2, M, a_rowoff=pl["c2_rowoff"], act=_lib.ACT_GELU, residual=self.pos_emb,
-                   ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D,
-                   out_act=pl["xa"], stat_out=pl["px0"], stat_groups=pl["first_groups"])
+                   ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D)
         self._run_layers(pl, states, pl["first_groups"], B, T2)
         return HiddenStates(states, pl["frame_offs_host"])
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_binding_covers_header(built_library):
     from interspeech_ser_amd import _lib
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
-    assert _lib.lib.ser_version() == _lib.ABI_VERSION == 9
+    assert _lib.lib.ser_version() == _lib.ABI_VERSION == int(re.search(r"#define SER_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
 
 
 def test_struct_layouts_match_c(built_library, tmp_path):

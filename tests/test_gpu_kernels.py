@@ -78,6 +78,12 @@ def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
     if kw.get("stat_out") is not None:
         g.stat_out, g.stat_groups = kw["stat_out"].data_ptr(), kw["stat_out"].shape[1]
     g.tile_cfg = kw.get("tile_cfg", 0)
+    if kw.get("shift_out") is not None:
+        rs, si = kw.get("shift_stats"), kw.get("shift_in")
+        g.shift_stats, g.shift_groups = (rs.data_ptr(), rs.shape[1]) if rs is not None else (None, 0)
+        g.shift_cols = kw.get("shift_cols", N)
+        g.shift_in = si.data_ptr() if si is not None else None
+        g.shift_out, g.shift_const = kw["shift_out"].data_ptr(), kw.get("shift_const", 0.0)
     L.check(L.lib.ser_gemm(C.byref(g), stream()), "ser_gemm")
     torch.cuda.synchronize()
     return out_f32, out_act
@@ -164,6 +170,60 @@ def test_gemm_row_stats_and_deferred_layernorm(L, mode, cfg):
     out, _ = run_gemm(L, x_act, Wp, M, N2, D, mode, bias=t, ln_stats=stat, ln_groups=G, ln_colsum=colsum, tile_cfg=cfg)
     err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < (3e-2 if mode == 1 else 5e-5), err
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_shifted_operand_chain_large_row_mean(L, mode, cfg):
+    """Rows whose mean is ~50 standard deviations (an offset living in the residual stream): ser_row_center gives the
+    first centred copy, a producer GEMM (residual + bias with a uniform offset) carries the shift forward from the
+    residual's row partials, and the consumer's deferred LayerNorm -- which never sees the shift, LayerNorm being
+    shift invariant -- matches fp64.  Unshifted, bf16(x) alone would be off by 50 * 2^-9 = 10 % of a standard deviation."""
+    M, D, N2 = 300, 320, 136
+    g = torch.Generator().manual_seed(5 + cfg)
+    x0 = torch.randn(M, D, generator=g) + 50.0 + torch.randn(M, 1, generator=g) * 20
+    planes = 2 if mode == 2 else 1
+    x0_act = torch.zeros((planes, M, D), dtype=torch.bfloat16, device=DEV)
+    st0 = torch.full((M, 2, 2), float("nan"), device=DEV)
+    sh0 = torch.zeros(M, device=DEV)
+    L.check(L.lib.ser_row_center(x0.to(DEV).data_ptr(), D, x0_act.data_ptr(), D, M * D, st0.data_ptr(), 2, sh0.data_ptr(),
+                                 mode, M, D, stream()), "ser_row_center")
+    torch.cuda.synchronize()
+    mean0 = x0.double().mean(1)
+    assert (sh0.cpu().double() - mean0).abs().max() < 1e-4
+    cen = x0.double() - sh0.cpu().double()[:, None]
+    assert (act_value(x0_act).cpu().double() - cen).abs().max() < (2e-2 if mode == 1 else 2e-4)
+    assert (st0.cpu().double()[:, 0, 1] - (cen * cen).sum(1)).abs().max() < 1e-2 and float(st0[:, 1].abs().max()) == 0.0
+    # producer: x1 = x0 + A W^T + b, b carries a uniform +3
+    A0 = torch.randn(M, 128, generator=g)
+    W0 = torch.randn(D, 128, generator=g) / math.sqrt(128)
+    b0 = torch.randn(D, generator=g) * 0.1 + 3.0
+    G = (D + 63) // 64
+    G += G & 1
+    stat = torch.zeros(M, G, 2, device=DEV)
+    sh1 = torch.zeros(M, device=DEV)
+    x1_f32, x1_act = run_gemm(L, to_act(A0, mode), to_act(W0, mode), M, D, 128, mode, bias=b0.to(DEV), residual=x0.to(DEV), ldr=D,
+                              want_act=True, stat_out=stat, tile_cfg=cfg, shift_stats=st0, shift_in=sh0, shift_out=sh1,
+                              shift_const=float(b0.double().mean()), shift_cols=D)
+    x1 = x1_f32.cpu().double()
+    c1 = sh1.cpu().double()
+    assert (c1 - (mean0 + b0.double().mean())).abs().max() < 1e-3               # shift = mean(residual row) + mean(bias)
+    assert (x1.mean(1) - c1).abs().max() < 1.0                                    # ... which tracks the true row mean
+    assert (act_value(x1_act).cpu().double() - (x1 - c1[:, None])).abs().max() < (3e-2 if mode == 1 else 3e-4)
+    ssum = stat.cpu().double().sum(1)
+    assert (ssum[:, 0] - (x1 - c1[:, None]).sum(1)).abs().max() < 1e-2
+    # consumer: LayerNorm(x1) W^T + b from the shifted copy and its partials
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    W = torch.randn(N2, D, generator=g) / math.sqrt(D)
+    b = torch.randn(N2, generator=g)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x1, (D,), gamma.double(), beta.double(), 1e-5),
+                                     W.double(), b.double())
+    Wp = to_act((W.double() * gamma.double()[None, :]).float(), mode)
+    colsum = act_value(Wp).double().sum(1).float().contiguous()
+    t = (W.double() @ beta.double() + b.double()).float().to(DEV)
+    out, _ = run_gemm(L, x1_act, Wp, M, N2, D, mode, bias=t, ln_stats=stat, ln_groups=G, ln_colsum=colsum, tile_cfg=cfg)
+    err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (3e-2 if mode == 1 else 1e-4), err
 
 
 @pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 2e-5)])
