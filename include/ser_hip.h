@@ -23,7 +23,8 @@
  *     whose utterance b owns rows frame_offs[b] .. frame_offs[b+1]-1;
  *   - "act" tensors feed matrix-core GEMMs: bf16, row-major, 1 plane (SER_MODE_BF16) or
  *     2 planes hi/lo with x ~= hi + lo (SER_MODE_FP32X, the 3-product split that gives
- *     fp32-grade results on the bf16 MFMA pipe); plane p lives at base + p*plane_stride;
+ *     fp32-grade results on the bf16 MFMA pipe), or 1 plane of fp16 (SER_MODE_FP16);
+ *     plane p lives at base + p*plane_stride;
  *   - the residual stream / hidden states are fp32 row-major [rows, D].
  */
 #ifndef SER_HIP_H
@@ -40,6 +41,9 @@ extern "C" {
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
+#define SER_MODE_FP16  3   /* act tensors have 1 plane of IEEE fp16 (11 significand bits, saturated at +-65504);
+                            * GEMMs do 1 f16 MFMA product -- same rate as bf16, 8x finer operand rounding.  The host
+                            * runs the conv stem in FP32X and the encoder layers in FP16 ("f16" numerics mode) */
 
 #define SER_ACT_NONE 0
 #define SER_ACT_GELU 1     /* exact erf GELU (ACT2FN["gelu"]) */
@@ -129,18 +133,19 @@ typedef struct ser_gemm_args {
     int32_t        col_scale_end;  /* multiple of 4; 0 = no scaling */
     /* SHIFTED operand copy for the deferred LayerNorm.  Real checkpoints carry offsets in the residual stream (rows
      * whose mean is many standard deviations); rounding such a row to bf16 and then forming acc - mu*colsum loses the
-     * signal.  With shift_out != NULL the launch computes, per row,
-     *   c[m] = shift_const + (shift_in ? shift_in[m] : 0) + (shift_stats ? sum_g shift_stats[m][g][0] / shift_cols : 0)
-     * i.e. the absolute row mean of its RESIDUAL input (whose row partials were written relative to shift_in) plus a
-     * load-time constant (mean of the bias), stores it in shift_out[m], and writes out_act and stat_out for v - c[m]
-     * (out_f32 keeps v).  LayerNorm is shift invariant, so the consuming GEMM is unchanged. */
-    const float*   shift_stats;    /* [M][shift_groups][2] row partials of the residual rows, or NULL */
-    int32_t        shift_groups;   /* even */
-    int32_t        shift_cols;     /* columns of a residual row (divisor of the partial sums) */
-    const float*   shift_in;       /* [M] shift the residual's partials are relative to, or NULL (0) */
+     * signal.  With shift_out != NULL a PRODUCER launch takes, per row,
+     *   c[m] = shift_const + (shift_in ? shift_in[m] : 0)
+     * -- shift_in = the absolute row mean of its RESIDUAL input, shift_const = a load-time constant (mean of the bias) --
+     * stores it in shift_out[m] and writes out_act and stat_out for v - c[m] (out_f32 keeps v).  LayerNorm is shift
+     * invariant, so the CONSUMER only has to report the absolute mean for the next producer down the residual stream:
+     * mean_out[m] = mu_m + (ln_shift ? ln_shift[m] : 0), where mu_m is the mean it derives from ln_stats_in (relative
+     * to the shift ln_shift its A rows were stored with). */
+    const float*   shift_in;       /* [M] absolute row mean of the residual rows, or NULL (0) */
     float*         shift_out;      /* [M] or NULL (no shifting) */
     float          shift_const;
     int32_t        reserved1;
+    const float*   ln_shift;       /* [M] shift of the A rows / their partials (consumer), or NULL */
+    float*         mean_out;       /* [M] absolute row mean of the A rows (consumer), or NULL */
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
 

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("SER_HIP_LIB") or os.path.join(_HERE, "lib", "libserhi
 
 MODE_BF16 = 1
 MODE_FP32X = 2
+MODE_FP16 = 3
 ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
@@ -43,8 +44,8 @@ class GemmArgs(C.Structure):
         ("ln_stats_in", c_void_p), ("ln_groups", C.c_int32), ("ln_colsum", c_void_p),
         ("stat_out", c_void_p), ("stat_groups", C.c_int32), ("f32_col_begin", C.c_int32),
         ("col_scale", c_float), ("col_scale_end", C.c_int32),
-        ("shift_stats", c_void_p), ("shift_groups", C.c_int32), ("shift_cols", C.c_int32),
         ("shift_in", c_void_p), ("shift_out", c_void_p), ("shift_const", c_float), ("reserved1", C.c_int32),
+        ("ln_shift", c_void_p), ("mean_out", c_void_p),
     ]
 
 

@@ -166,7 +166,7 @@ void attention_kernel(const AttnParams p) {
         } else {
             // gate pre-activations ride along as two extra columns per head of the packed projection
             const unsigned short* gp = p.qkv + (int64_t)(row0 + qc) * p.ld + p.gate_col + 2 * h;
-            g_in0 = bf2f(gp[0]); g_in1 = bf2f(gp[1]);
+            g_in0 = elem2f<MODE>(gp[0]); g_in1 = elem2f<MODE>(gp[1]);
             if (NP == 2) { g_in0 += bf2f(gp[p.plane]); g_in1 += bf2f(gp[p.plane + 1]); }
             g_c = p.gru_const[h];
         }
@@ -265,7 +265,7 @@ void attention_kernel(const AttnParams p) {
             for (int ks = 0; ks < KS; ++ks)                          // the two key halves are independent chains
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
-                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[0][ks], st[sub], 0, 0, 0);
+                    st[sub] = mfma32<MODE>(kf[sub][ks], qf[0][ks], st[sub]);
         } else {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -286,7 +286,7 @@ void attention_kernel(const AttnParams p) {
                 for (int ks = 0; ks < KS; ++ks) {
                     const int off = key * RS + (k_swz<DHP>(key, ks * 2 + hh) << 4);
                     const bf16x8 kh = *(const bf16x8*)(ldsK + off);
-                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ks], st[sub], 0, 0, 0);
+                    st[sub] = mfma32<MODE>(kh, qf[0][ks], st[sub]);
                     if (NP == 2) {
                         const bf16x8 kl = *(const bf16x8*)(ldsK + TILE + off);
                         st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ks], st[sub], 0, 0, 0);
@@ -359,20 +359,31 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 ph, plo;
+                if constexpr (MODE == SER_MODE_FP16) {
+                    f16x8 p16;                                       // P in [0, 1]: no saturation needed
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
-                    lsum += e;
-                    const __bf16 hi = (__bf16)e;
-                    ph[j] = hi;
-                    if (NP == 2) plo[j] = (__bf16)(e - (float)hi);
+                    for (int j = 0; j < 8; ++j) {
+                        const float e = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
+                        lsum += e;
+                        p16[j] = (_Float16)e;
+                    }
+                    ph = __builtin_bit_cast(bf16x8, p16);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float e = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
+                        lsum += e;
+                        const __bf16 hi = (__bf16)e;
+                        ph[j] = hi;
+                        if (NP == 2) plo[j] = (__bf16)(e - (float)hi);
+                    }
                 }
 #pragma unroll
                 for (int ds = 0; ds < DSUB; ++ds) {
                     bf16x8 vh;
                     if constexpr (WIDE) vh = vfr[sub][s2][ds];
                     else vh = v_frag(ldsV, sub, s2, ds);
-                    ot[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[ds], 0, 0, 0);
+                    ot[ds] = mfma32<MODE>(vh, ph, ot[ds]);
                     if (NP == 2) {
                         const bf16x8 vl = v_frag(ldsV + TILE, sub, s2, ds);
                         ot[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[ds], 0, 0, 0);
@@ -441,7 +452,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
     if ((ld % 8) || (ldo % 4) || (q_col % 8) || (k_col % 8) || (v_col % 8)) return ser_fail(-4, "ser_attention: misaligned pitches/columns");
-    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-5, "ser_attention: bad mode %d", mode);
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X && mode != SER_MODE_FP16) return ser_fail(-5, "ser_attention: bad mode %d", mode);
     if ((table != nullptr) != (gate != nullptr || gru_const != nullptr))
         return ser_fail(-6, "ser_attention: the bias table needs a gate (gate[] or gate_col + gru_const) and vice versa");
     if (gate && gru_const) return ser_fail(-9, "ser_attention: give gate[] or gru_const, not both");
@@ -452,7 +463,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     // 8-wave blocks: -1.1 us per launch in isolation (24.4 -> 23.3 us at 8 x 499 frames), +1.2 % on the real step
     // (512-thread blocks leave no room for the other utterance group's blocks on the CU): off unless SER_ATTN_W8=1
     static const int w8_knob = [] { const char* e = getenv("SER_ATTN_W8"); return e ? atoi(e) : 0; }();
-    const int nwv = (w8_knob && np == 1 && dhp == 64 && max_frames > ABQ) ? 8 : 4;
+    const int nwv = (w8_knob && mode == SER_MODE_BF16 && dhp == 64 && max_frames > ABQ) ? 8 : 4;
     const int nch = ABKV * (dhp / 8) / (64 * nwv);
     const int nbuf = (nch * 2 * np <= 8) ? 2 : 1;
     // copy stride == 16 (mod 64) floats: the 4 shifted copies x the 4 query phases of a ds_read_b128
@@ -477,9 +488,10 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     const bool pre = scale <= 0.f;
 #define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
                               : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
-    if (dhp == 64 && np == 1 && nwv == 8)
+    if (dhp == 64 && mode == SER_MODE_BF16 && nwv == 8)
         return pre ? (table ? launch_attention<64, SER_MODE_BF16, true, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, true, false, 8>(p, grid, lds, s))
                    : (table ? launch_attention<64, SER_MODE_BF16, false, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, false, false, 8>(p, grid, lds, s));
+    if (mode == SER_MODE_FP16) return dhp == 64 ? SER_ATTN(64, SER_MODE_FP16) : SER_ATTN(128, SER_MODE_FP16);
     if (dhp == 64 && np == 1) return SER_ATTN(64, SER_MODE_BF16);
     if (dhp == 64) return SER_ATTN(64, SER_MODE_FP32X);
     if (np == 1) return SER_ATTN(128, SER_MODE_BF16);

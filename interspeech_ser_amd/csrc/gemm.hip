@@ -192,31 +192,6 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     // deferred LayerNorm: row mean / rstd of the A rows from the producer's partial sums, into the
     // LDS words behind the ring (one row per thread; the loads fly beside the first DMA tiles)
     float* lnst = (float*)(lds + ST * STAGE);                         // [BM][2]
-    float* shf = lnst + 2 * BM;                                       // [BM] shift of the act copy / row partials
-    // SHIFTED operand copy (see ser_hip.h): c[m] = absolute row mean of the residual input (+ a load-time constant).
-    // The act copy and the row partials this launch writes hold v - c[m], so rows whose mean is many standard
-    // deviations (offsets living in the residual stream) still round to bf16 relative to their spread, and the
-    // consumer's E[x^2] - mean^2 does not cancel.  LayerNorm is shift invariant: the consumer needs no change.
-    if (p.shift_out) {
-        for (int r = tid; r < BM; r += NT) {
-            int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
-            float c = p.shift_const;
-            if (p.shift_in) c += p.shift_in[m];
-            if (p.shift_stats) {
-                const float* ps = p.shift_stats + (int64_t)m * p.shift_groups * 2;
-                float s1 = 0.f;
-                for (int u = 0; u < p.shift_groups; u += 2) {
-                    const f32x4 pv = *(const f32x4*)(ps + 2 * u);
-                    s1 += pv[0] + pv[2];
-                }
-                c += s1 / (float)p.shift_cols;
-            }
-            shf[r] = c;
-            if (nt == 0 && g == 0 && m0 + r < p.M) p.shift_out[m] = c;
-        }
-        if (!p.ln_stats_in) __syncthreads();
-    }
     if (p.ln_stats_in) {
         for (int r = tid; r < BM; r += NT) {
             int m = m0 + r;
@@ -235,6 +210,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             const float var = fmaxf(s2 * invK - mu * mu, 0.f);
             lnst[2 * r] = mu;
             lnst[2 * r + 1] = rsqrtf(var + p.ln_eps);
+            // absolute row mean of the A rows (their partials are relative to ln_shift): the next producer's shift
+            if (p.mean_out && nt == 0 && g == 0 && m0 + r < p.M) p.mean_out[m] = mu + (p.ln_shift ? p.ln_shift[m] : 0.f);
         }
         __syncthreads();
     }
@@ -276,7 +253,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][ni], af[s][mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = mfma16<MODE>(wf[s][ni], af[s][mi], acc[ni][mi]);
                 __builtin_amdgcn_s_setprio(0);
             }
         } else {
@@ -398,6 +375,20 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         // most launches use neither (the epilogue is VALU-bound where it carries a GELU)
         const bool do_scale = p.col_scale_end > 0;
         const bool do_stat = p.stat_out != nullptr;
+        // SHIFTED operand copy (ser_hip.h): c[m] = absolute row mean of the residual input + a load-time constant.  The
+        // act copy and the row partials written below hold v - c[m], so rows whose mean is many standard deviations
+        // (offsets living in the residual stream) still round to bf16 relative to their spread, and the consumer's
+        // E[x^2] - mean^2 does not cancel.  LayerNorm is shift invariant: the consumer needs no change.
+        float cs[TM];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            cs[mi] = 0.f;
+            if (p.shift_out) {
+                int m = m0 + wm * TM * 16 + mi * 16 + frow;
+                m = m < p.M ? m : p.M - 1;
+                cs[mi] = p.shift_const + (p.shift_in ? p.shift_in[m] : 0.f);
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
             const int m = m0 + wm * TM * 16 + mi * 16 + frow;
@@ -409,7 +400,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 mu = lnst[2 * (wm * TM * 16 + mi * 16 + frow)];
                 rs = lnst[2 * (wm * TM * 16 + mi * 16 + frow) + 1];
             }
-            const float cshift = p.shift_out ? shf[wm * TM * 16 + mi * 16 + frow] : 0.f;
+            const float cshift = cs[mi];
+            if (p.shift_out && nt == 0 && g == 0 && wn == 0 && fq == 0) p.shift_out[m] = cshift;
             float st1 = 0.f, st2 = 0.f;
 #pragma unroll
             for (int ni = 0; ni < TN; ni += 2) {                      // fragment column blocks ni, ni+1: 4 + 4 columns
@@ -480,32 +472,35 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 // ------------------------------------------------------------------------------------------------
 enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN512_M64 = 4, CFG_LN512_M32 = 5, CFG_128x64 = 6 };
 
-template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI>
+template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI>
+static hipError_t launch_mode(const ser_gemm_args* a, dim3 grid, dim3 block, int LDS, hipStream_t s) {
+    auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, MODE, LNEPI>;
+    static bool ready = false;                     // per instantiation; benign race (idempotent call)
+    if (LDS > 65536 && !ready) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        ready = true;
+    }
+    hipLaunchKernelGGL(k, grid, block, LDS, s, *a);
+    return hipSuccess;
+}
+
+// X32: the configuration serves FP32X (two planes per stage); otherwise the single-plane modes BF16 / FP16.
+template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI, bool X32 = false>
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const int npl = (a->mode == SER_MODE_FP32X) ? 2 : 1;
-    const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 12);  // ring (+ [BM][2] row statistics + [BM] row shift)
+    const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8);   // ring (+ [BM][2] row statistics)
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
-    if (a->mode == SER_MODE_BF16) {
-        auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, SER_MODE_BF16, LNEPI>;
-        static bool ready = false;                 // per instantiation; benign race (idempotent call)
-        if (LDS > 65536 && !ready) {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
-            ready = true;
-        }
-        hipLaunchKernelGGL(k, grid, block, LDS, s, *a);
+    hipError_t e = hipSuccess;
+    if constexpr (X32) {
+        e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>(a, grid, block, LDS, s);
     } else {
-        auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>;
-        static bool ready = false;
-        if (LDS > 65536 && !ready) {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
-            ready = true;
-        }
-        hipLaunchKernelGGL(k, grid, block, LDS, s, *a);
+        if (a->mode == SER_MODE_FP16) e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16, LNEPI>(a, grid, block, LDS, s);
+        else e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_BF16, LNEPI>(a, grid, block, LDS, s);
     }
+    if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
     return ser_check_launch("ser_gemm");
 }
 
@@ -566,7 +561,7 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->K % 64) return ser_fail(-3, "ser_gemm: K=%d must be a multiple of 64", a->K);
     if (a->kc && (a->kc % 64 || a->K % a->kc)) return ser_fail(-4, "ser_gemm: kc=%d must divide K and be a multiple of 64", a->kc);
     if (a->N % 8) return ser_fail(-5, "ser_gemm: N=%d must be a multiple of 8", a->N);
-    if (a->mode != SER_MODE_BF16 && a->mode != SER_MODE_FP32X) return ser_fail(-6, "ser_gemm: bad mode %d", a->mode);
+    if (a->mode != SER_MODE_BF16 && a->mode != SER_MODE_FP32X && a->mode != SER_MODE_FP16) return ser_fail(-6, "ser_gemm: bad mode %d", a->mode);
     if (!a->a_rowoff && (a->lda % 8)) return ser_fail(-7, "ser_gemm: lda must be a multiple of 8");
     if (a->groups < 1) return ser_fail(-8, "ser_gemm: groups=%d", a->groups);
     if (!a->out_f32 && !a->out_act) return ser_fail(-9, "ser_gemm: no output");
@@ -583,11 +578,8 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     }
     if (a->stat_out && (a->ln_gamma || a->stat_groups < a->groups * ((a->N + 63) / 64)))
         return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
-    if (a->shift_out) {
-        if (!a->stat_out || a->ln_gamma) return ser_fail(-19, "ser_gemm: shift_out needs stat_out and no fused-LN epilogue");
-        if (a->shift_stats && (a->shift_groups < 2 || (a->shift_groups & 1) || a->shift_cols <= 0))
-            return ser_fail(-19, "ser_gemm: shift_stats needs an even shift_groups >= 2 and shift_cols > 0");
-    }
+    if (a->shift_out && (!a->stat_out || a->ln_gamma)) return ser_fail(-19, "ser_gemm: shift_out needs stat_out and no fused-LN epilogue");
+    if (a->mean_out && !a->ln_stats_in) return ser_fail(-20, "ser_gemm: mean_out needs ln_stats_in");
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
     if ((a->ldo_act % 8) || (a->c_group_stride % 8)) return ser_fail(-18, "ser_gemm: act pitch / group stride must be multiples of 8");
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
@@ -595,8 +587,8 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (a->mode == SER_MODE_FP32X) {
         // both planes share a stage: the ring doubles, so FP32X uses the two configurations that still fit 160 KiB
-        if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true>(a, s);
-        return launch_cfg<4, 2, 2, 4, 64, 2, false>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
+        if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true, true>(a, s);
+        return launch_cfg<4, 2, 2, 4, 64, 2, false, true>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
     }
     switch (pick_cfg(a)) {
         case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 64, 2, true>(a, s);     // 160 KiB ring, one barrier per 64-deep K tile

@@ -314,6 +314,9 @@ extern "C" int ser_layernorm(const float* x, int64_t ldx, const float* g, const 
     else if (mode == SER_MODE_BF16)
         hipLaunchKernelGGL(layernorm_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
                            out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
+    else if (mode == SER_MODE_FP16)
+        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_FP16>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
+                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
     else return ser_fail(-4, "ser_layernorm: bad mode %d", mode);
     return ser_check_launch("ser_layernorm");
 }
@@ -371,6 +374,9 @@ extern "C" int ser_row_center(const float* x, int64_t ldx, void* out_act, int64_
                            (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
     else if (mode == SER_MODE_BF16)
         hipLaunchKernelGGL(row_center_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
+    else if (mode == SER_MODE_FP16)
+        hipLaunchKernelGGL(row_center_kernel<SER_MODE_FP16>, grid, block, 0, (hipStream_t)stream, x, ldx,
                            (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
     else return ser_fail(-4, "ser_row_center: bad mode %d", mode);
     return ser_check_launch("ser_row_center");
@@ -555,15 +561,19 @@ extern "C" int ser_mean4(const float* s0, const float* s1, const float* s2, cons
 }
 
 // ------------------------------------------------------------------- weights / packing
-__global__ void split_kernel(const float* __restrict__ x, unsigned short* __restrict__ o, int64_t plane, int two,
+__global__ void split_kernel(const float* __restrict__ x, unsigned short* __restrict__ o, int64_t plane, int mode,
                              int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += step) {
+        if (mode == SER_MODE_FP16) {
+            o[i] = (unsigned short)(pack_h2(x[i], 0.f) & 0xffffu);
+            continue;
+        }
         unsigned short h, l;
         split_bf(x[i], h, l);
         o[i] = h;
-        if (two) o[plane + i] = l;
+        if (mode == SER_MODE_FP32X) o[plane + i] = l;
     }
 }
 
@@ -596,7 +606,7 @@ extern "C" int ser_split_bf16(const float* x, void* out, int64_t plane_stride, i
     int64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
-                       (unsigned short*)out, plane_stride, mode == SER_MODE_FP32X ? 1 : 0, n);
+                       (unsigned short*)out, plane_stride, mode, n);
     return ser_check_launch("ser_split_bf16");
 }
 

@@ -5,6 +5,8 @@
 #include "../../include/ser_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -26,6 +28,29 @@ __device__ __forceinline__ float bf2f(unsigned short h) {
 }
 __device__ __forceinline__ unsigned int pack_bf2(float a, float b) {
     return (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
+}
+// fp16 operands (SER_MODE_FP16): 11 significand bits instead of bf16's 8 at the same MFMA rate.  The range is the
+// price: values are saturated at +-65504 on the way in (a raw residual row of a real checkpoint stays far below).
+__device__ __forceinline__ unsigned int pack_h2(float a, float b) {
+    const float lim = 65504.0f;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    const f2 v = {__builtin_amdgcn_fmed3f(a, -lim, lim), __builtin_amdgcn_fmed3f(b, -lim, lim)};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2));   // v_cvt_pk_f16_f32, RNE
+}
+__device__ __forceinline__ float h2f(unsigned short h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+// one 16-bit operand element -> fp32, in the format of MODE's planes
+template <int MODE>
+__device__ __forceinline__ float elem2f(unsigned short h) {
+    if (MODE == SER_MODE_FP16) return h2f(h);
+    return bf2f(h);
+}
+// two fp32 -> one packed pair of MODE's 16-bit operand format (single-plane modes)
+template <int MODE>
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+    if (MODE == SER_MODE_FP16) return pack_h2(a, b);
+    return pack_bf2(a, b);
 }
 // x ~= hi + lo with both halves bf16: 16 significand bits survive.
 __device__ __forceinline__ void split_bf(float x, unsigned short& hi, unsigned short& lo) {
@@ -107,6 +132,20 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
     else return gelu_erf2(v);
 }
 
+// One MFMA step on 8 + 8 operand elements per lane in MODE's 16-bit format (same lane maps for bf16 and f16).
+template <int MODE>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if (MODE == SER_MODE_FP16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int MODE>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (MODE == SER_MODE_FP16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -122,8 +161,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // pointer `dst` (8-byte aligned).  `plane` = element distance to the lo plane.
 template <int MODE>
 __device__ __forceinline__ void store_act4(unsigned short* dst, int64_t plane, float a, float b, float c, float d) {
-    if (MODE == SER_MODE_BF16) {
-        u32x2 v = {pack_bf2(a, b), pack_bf2(c, d)};
+    if (MODE != SER_MODE_FP32X) {
+        u32x2 v = {pack2<MODE>(a, b), pack2<MODE>(c, d)};
         *(u32x2*)dst = v;
     } else {
         unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
@@ -139,8 +178,8 @@ __device__ __forceinline__ void store_act4(unsigned short* dst, int64_t plane, f
 // instructions of two store_act4 -- epilogue store tails are issue-bound, not bandwidth-bound.
 template <int MODE>
 __device__ __forceinline__ void store_act8(unsigned short* dst, int64_t plane, const float (&v)[8]) {
-    if (MODE == SER_MODE_BF16) {
-        u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    if (MODE != SER_MODE_FP32X) {
+        u32x4 o = {pack2<MODE>(v[0], v[1]), pack2<MODE>(v[2], v[3]), pack2<MODE>(v[4], v[5]), pack2<MODE>(v[6], v[7])};
         *(u32x4*)dst = o;
     } else {
         unsigned short h[8], l[8];
@@ -165,9 +204,9 @@ __device__ __forceinline__ void store_act8(unsigned short* dst, int64_t plane, c
 // dst already points at this lane's 8-column run; every lane of the pair must call (ok only gates the store).
 template <int MODE>
 __device__ __forceinline__ void store_act8_swap(unsigned short* dst, int64_t plane, bool ok, const float (&v)[8]) {
-    if (MODE == SER_MODE_BF16) {
-        const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf2(v[0], v[1]), pack_bf2(v[4], v[5]), false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf2(v[2], v[3]), pack_bf2(v[6], v[7]), false, false);
+    if (MODE != SER_MODE_FP32X) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<MODE>(v[0], v[1]), pack2<MODE>(v[4], v[5]), false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<MODE>(v[2], v[3]), pack2<MODE>(v[6], v[7]), false, false);
         if (ok) *(u32x4*)dst = (u32x4){s0[0], s1[0], s0[1], s1[1]};
     } else {
         unsigned short h[8], l[8];
@@ -194,6 +233,14 @@ __device__ __forceinline__ void store_act8_swap(unsigned short* dst, int64_t pla
 template <int MODE>
 __device__ __forceinline__ void load_act8(const unsigned short* src, int64_t plane, float (&v)[8]) {
     u32x4 h = *(const u32x4*)src;
+    if (MODE == SER_MODE_FP16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = h2f((unsigned short)(h[i] & 0xffffu));
+            v[2 * i + 1] = h2f((unsigned short)(h[i] >> 16));
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         v[2 * i] = __uint_as_float(h[i] << 16);

@@ -29,7 +29,16 @@ from . import _lib
 from ._lib import GemmArgs, check, lib
 from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
-MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X}
+MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16}
+# "f16": encoder layers on single-product fp16 operands (11 significand bits at the bf16 MFMA rate), the convolutional
+# stem -- where operand rounding hurts most and only 13 % of the FLOPs live -- on the 3-product FP32X split.
+_PLANES = {_lib.MODE_BF16: 1, _lib.MODE_FP32X: 2, _lib.MODE_FP16: 1}
+_DTYPE = {_lib.MODE_BF16: torch.bfloat16, _lib.MODE_FP32X: torch.bfloat16, _lib.MODE_FP16: torch.float16}
+
+
+# A/B knob (tools/): SER_NO_SHIFT=1 turns the shifted operand copy of the encoder layers off (state 0 is still centred)
+import os as _os
+_NO_SHIFT = _os.environ.get("SER_NO_SHIFT", "0") == "1"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -98,11 +107,12 @@ def _on_stream(fn):
 
 
 class Act:
-    """bf16 GEMM operand with 1 (bf16) or 2 (hi/lo) planes: tensor [planes, rows, cols]."""
+    """16-bit GEMM operand with 1 (bf16 / fp16) or 2 (bf16 hi/lo) planes: tensor [planes, rows, cols]."""
 
-    def __init__(self, rows: int, cols: int, planes: int, device, zero: bool = False, extra_rows: int = 0):
+    def __init__(self, rows: int, cols: int, planes: int, device, zero: bool = False, extra_rows: int = 0,
+                 dtype=torch.bfloat16):
         alloc = torch.zeros if zero else torch.empty
-        self.t = alloc((planes, rows + extra_rows, cols), dtype=torch.bfloat16, device=device)
+        self.t = alloc((planes, rows + extra_rows, cols), dtype=dtype, device=device)
         self.rows, self.cols, self.planes = rows, cols, planes
         self.plane_stride = (rows + extra_rows) * cols
 
@@ -156,8 +166,9 @@ class _EncoderBase:
         self.geo = geo
         self.device = torch.device(device)
         self.mode_name = mode
-        self.mode = MODES[mode]
-        self.planes = 2 if mode == "fp32x" else 1
+        self.mode = MODES[mode]                                   # encoder layers
+        self.stem_mode = _lib.MODE_FP32X if mode == "f16" else self.mode      # conv stem (+ projection, positional conv)
+        self.planes, self.stem_planes = _PLANES[self.mode], _PLANES[self.stem_mode]
         self._cache: Dict = {}
         # when a list, every ser_gemm launch appends (start_event, end_event, algorithmic_flops):
         # bench.py uses it for the live roofline figure of the dominant kernel
@@ -176,13 +187,14 @@ class _EncoderBase:
     def _dev_f32(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(torch.float32).contiguous().to(self.device)
 
-    def _linear(self, w: torch.Tensor, b: Optional[torch.Tensor]) -> Linear:
-        """fp32 [N, K] -> bf16 hi (+ lo) planes on the device (ser_split_bf16)."""
+    def _linear(self, w: torch.Tensor, b: Optional[torch.Tensor], stem: bool = False) -> Linear:
+        """fp32 [N, K] -> 16-bit operand planes on the device (ser_split_bf16): bf16 hi (+ lo), or fp16."""
         w = w.detach().to(torch.float32).contiguous()
         N, K = w.shape
         src = w.to(self.device)
-        out = torch.empty((self.planes, N, K), dtype=torch.bfloat16, device=self.device)
-        check(lib.ser_split_bf16(src.data_ptr(), out.data_ptr(), N * K, self.mode, N * K, _stream()), "ser_split_bf16")
+        mode = self.stem_mode if stem else self.mode
+        out = torch.empty((_PLANES[mode], N, K), dtype=_DTYPE[mode], device=self.device)
+        check(lib.ser_split_bf16(src.data_ptr(), out.data_ptr(), N * K, mode, N * K, _stream()), "ser_split_bf16")
         torch.cuda.current_stream().synchronize()
         return Linear(out, None if b is None else self._dev_f32(b), N, K)
 
@@ -199,8 +211,9 @@ class _EncoderBase:
         lin.colsum = lin.w.double().sum(dim=(0, 2)).float().contiguous()
         return lin
 
-    def _new_act(self, rows, cols, zero=False, extra_rows=0) -> Act:
-        return Act(rows, cols, self.planes, self.device, zero=zero, extra_rows=extra_rows)
+    def _new_act(self, rows, cols, zero=False, extra_rows=0, stem=False) -> Act:
+        mode = self.stem_mode if stem else self.mode
+        return Act(rows, cols, _PLANES[mode], self.device, zero=zero, extra_rows=extra_rows, dtype=_DTYPE[mode])
 
     # ------------------------------------------------------------------ launchers
     def _gemm(self, a: Act, lin: Linear, M: int, *, a_rowoff=None, lda=None, kc=0, ldj=0, groups=1,
@@ -208,7 +221,7 @@ class _EncoderBase:
               residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
               out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0,
               ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0,
-              col_scale=1.0, col_scale_end=0, shift=None):
+              col_scale=1.0, col_scale_end=0, shift=None, ln_mean=None, stem=False):
         rec = self._rec
         g = rec.slot("gemm") if rec is not None else GemmArgs()
         g.A = a.ptr + a_ptr_offset
@@ -221,7 +234,7 @@ class _EncoderBase:
         g.M, g.N, g.K = M, (lin.N if N is None else N), (lin.K if K is None else K)
         g.groups = groups
         g.a_group_stride, g.w_group_stride, g.c_group_stride = a_group_stride, w_group_stride, c_group_stride
-        g.mode = self.mode
+        g.mode = self.stem_mode if stem else self.mode
         g.bias = _ptr(lin.b)
         g.act = act
         g.residual = _ptr(residual)
@@ -243,10 +256,11 @@ class _EncoderBase:
             g.stat_out, g.stat_groups = stat_out.data_ptr(), stat_groups
         g.f32_col_begin = f32_col_begin
         g.col_scale, g.col_scale_end = float(col_scale), int(col_scale_end)
-        if shift is not None:                   # shifted operand copy (ser_hip.h): (residual stats, groups, shift_in, shift_out, const)
-            r_stats, r_groups, s_in, s_out, s_const = shift
-            g.shift_stats, g.shift_groups, g.shift_cols = _ptr(r_stats), int(r_groups), g.N * groups
+        if shift is not None:                   # producer side of the shifted operand copy (ser_hip.h): (mean of residual, shift_out, const)
+            s_in, s_out, s_const = shift
             g.shift_in, g.shift_out, g.shift_const = _ptr(s_in), s_out.data_ptr(), float(s_const)
+        if ln_mean is not None:                 # consumer side: (shift of the A rows, absolute row mean out)
+            g.ln_shift, g.mean_out = _ptr(ln_mean[0]), ln_mean[1].data_ptr()
         if rec is not None:
             rec.commit(_lib.OP_GEMM, g, M=M)
             return
@@ -260,14 +274,16 @@ class _EncoderBase:
         # algorithmic FLOPs: 2*M*N*K over real (unpadded) channels, no tile-padding FLOPs
         k_real = g.K if k_algo is None else k_algo
         # algorithmic HBM bytes: every operand / result element touched exactly once
-        nbytes = 2.0 * self.planes * (M * k_real * groups + g.N * groups * k_real)
+        planes = self.stem_planes if stem else self.planes
+        nbytes = 2.0 * planes * (M * k_real * groups + g.N * groups * k_real)
         nbytes += 4.0 * M * g.N * groups * ((residual is not None) + (out_f32 is not None))
-        nbytes += 2.0 * self.planes * M * g.N * groups * (out_act is not None)
+        nbytes += 2.0 * planes * M * g.N * groups * (out_act is not None)
         self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * k_real, nbytes))
 
     def _layernorm(self, x: torch.Tensor, ldx: int, ln, rows: int, D: int, *, gelu=False, out_f32=None,
-                   out_act: Optional[Act] = None, eps=None):
+                   out_act: Optional[Act] = None, eps=None, stem=False):
         g, b = ln
+        mode = self.stem_mode if stem else self.mode
         eps = float(self.geo.layer_norm_eps if eps is None else eps)
         o_act = None if out_act is None else out_act.ptr
         ldo_act = 0 if out_act is None else out_act.cols
@@ -278,11 +294,11 @@ class _EncoderBase:
             a = rec.slot("layernorm")
             a.x, a.ldx, a.g, a.b, a.eps, a.gelu = x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu)
             a.out_f32, a.ldo_f32, a.out_act, a.ldo_act, a.out_plane_stride = _ptr(out_f32), ldo_f32, o_act, ldo_act, ops
-            a.mode, a.rows, a.D = self.mode, rows, D
+            a.mode, a.rows, a.D = mode, rows, D
             rec.commit(_lib.OP_LAYERNORM, a, rows=rows)
             return
         check(lib.ser_layernorm(x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu), _ptr(out_f32), ldo_f32,
-                                o_act, ldo_act, ops, self.mode, rows, D, self._s()), "ser_layernorm")
+                                o_act, ldo_act, ops, mode, rows, D, self._s()), "ser_layernorm")
 
     def _row_center(self, x: torch.Tensor, out_act: Act, stats: torch.Tensor, shift: torch.Tensor, rows: int, D: int):
         """hidden_states[0] -> centred operand copy + row partials + shift for encoder layer 0 (ser_row_center)."""
@@ -327,14 +343,17 @@ class _EncoderBase:
         """Pre-LN / stable-LN encoder layers with BOTH LayerNorms deferred into the consuming GEMMs:
         x -> [QKV(+gate) GEMM: LN1 folded] -> attention -> [out GEMM +x -> h] -> [FC1 GEMM: LN2 folded, GELU]
           -> [FC2 GEMM +h -> next x].  Producers emit the bf16 operand copy and the row partial sums, both SHIFTED by
-        the row mean of their residual input (carried in sx / sh): offsets that live in the residual stream never
-        reach the bf16 rounding or the one-pass variance.  states[0] is centred once by ser_row_center."""
+        the row mean of their residual input: the consumer of x (QKV) reports x's absolute row mean (mx), the producer
+        of h (out-proj) shifts by it and records the shift (sh), the consumer of h (FC1) reports mh, the producer of
+        the next x (FC2) shifts by that (sx).  Offsets that live in the residual stream never reach the bf16 rounding or
+        the one-pass variance.  states[0] is centred once by ser_row_center."""
         geo = self.geo
         M, D, L = pl["M"], geo.hidden, geo.num_layers
         wavlm = geo.family == FAMILY_WAVLM
         gD = self._stat_groups(D)
         gx = first_groups
         self._row_center(states[0], pl["xa"], pl["px0"], pl["sx"], M, D)
+        shifted = not _NO_SHIFT
         for i, lay in enumerate(self.layers):
             x = states[i]
             last = i + 1 == L
@@ -344,7 +363,8 @@ class _EncoderBase:
                 b0.record()
             # q columns leave the projection already multiplied by dh^-0.5 * log2(e)
             self._gemm(pl["xa"], lay["qkv"], M, ln_stats=(pl["px0"] if i == 0 else pl["px"]), ln_groups=gx,
-                       out_act=pl["qkv"], col_scale=geo.head_dim ** -0.5 * 1.4426950408889634, col_scale_end=D)
+                       out_act=pl["qkv"], col_scale=geo.head_dim ** -0.5 * 1.4426950408889634, col_scale_end=D,
+                       ln_mean=(pl["sx"], pl["mx"]) if shifted else None)
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"],
                                 table_T=pl["Tmax"], gru_const=lay["gate_c"])
@@ -352,18 +372,19 @@ class _EncoderBase:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
             self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D,
                        out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD,
-                       shift=((pl["px0"] if i == 0 else pl["px"]), gx, pl["sx"], pl["sh"], lay["out_bias_mean"]))
+                       shift=(pl["mx"], pl["sh"], lay["out_bias_mean"]) if shifted else None)
             if self.block_trace is not None:
                 b1 = torch.cuda.Event(enable_timing=True)
                 b1.record()
                 self.block_trace.append((b0, b1, B))
-            self._gemm(pl["ha"], lay["fc1"], M, ln_stats=pl["ph"], ln_groups=gD, act=_lib.ACT_GELU, out_act=pl["ffn"])
+            self._gemm(pl["ha"], lay["fc1"], M, ln_stats=pl["ph"], ln_groups=gD, act=_lib.ACT_GELU, out_act=pl["ffn"],
+                       ln_mean=(pl["sh"], pl["mh"]) if shifted else None)
             if last:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
             else:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D,
                            out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD,
-                           shift=(pl["ph"], gD, pl["sh"], pl["sx"], lay["fc2_bias_mean"]))
+                           shift=(pl["mh"], pl["sx"], lay["fc2_bias_mean"]) if shifted else None)
             gx = gD
         self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
 
@@ -408,6 +429,8 @@ class _EncoderBase:
         pl["px0"] = torch.zeros((M, first_groups, 2), dtype=torch.float32, device=dev)   # states[0] (ser_row_center)
         pl["sx"] = torch.zeros(M, dtype=torch.float32, device=dev)       # row shift of the xa copy / px partials
         pl["sh"] = torch.zeros(M, dtype=torch.float32, device=dev)       # row shift of the ha copy / ph partials
+        pl["mx"] = torch.zeros(M, dtype=torch.float32, device=dev)       # absolute row mean of x (written by the QKV GEMM)
+        pl["mh"] = torch.zeros(M, dtype=torch.float32, device=dev)       # absolute row mean of h (written by the FC1 GEMM)
         pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
         pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
         pl["qkv"] = self._new_act(M, nqkv)
@@ -502,16 +525,16 @@ class SpeechEncoder(_EncoderBase):
             raise NotImplementedError("conv layer 0 kernel wider than 64 taps")
         w0 = torch.zeros((C0, 64), dtype=torch.float32)
         w0[:, : geo.conv_kernel[0]] = sd[p0 + ".conv.weight"].reshape(C0, geo.conv_kernel[0]).float()
-        self.conv0 = self._linear(w0, sd[p0 + ".conv.bias"] if geo.conv_bias else None)
+        self.conv0 = self._linear(w0, sd[p0 + ".conv.bias"] if geo.conv_bias else None, stem=True)
         self.conv_ln = [self._ln_pair(sd, f"feature_extractor.conv_layers.{i}.layer_norm") for i in range(len(geo.conv_dim))]
         self.convs: List[Linear] = []
         for i in range(1, len(geo.conv_dim)):
             p = f"feature_extractor.conv_layers.{i}.conv"
             w = sd[p + ".weight"].float()                                  # [Cout, Cin, k]
             w2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)                # K index = tap*Cin + c
-            self.convs.append(self._linear(w2, sd[p + ".bias"] if geo.conv_bias else None))
+            self.convs.append(self._linear(w2, sd[p + ".bias"] if geo.conv_bias else None, stem=True))
         self.proj_ln = self._ln_pair(sd, "feature_projection.layer_norm")
-        self.proj = self._linear(sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"])
+        self.proj = self._linear(sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"], stem=True)
         # positional conv: per group [Cg out][tap][Cg in padded to a multiple of 64]
         G, k = geo.pos_conv_groups, geo.pos_conv_kernel
         Cg = D // G
@@ -519,7 +542,7 @@ class SpeechEncoder(_EncoderBase):
         w = _fold_weight_norm(sd)                                          # [D, Cg, k]
         wp = torch.zeros((G, Cg, k, self.pos_kc), dtype=torch.float32)
         wp[:, :, :, :Cg] = w.view(G, Cg, Cg, k).permute(0, 1, 3, 2)
-        self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"])
+        self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"], stem=True)
         self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
         self.layers = []
         for i in range(geo.num_layers):
@@ -546,17 +569,17 @@ class SpeechEncoder(_EncoderBase):
         C0, D = geo.conv_dim[0], geo.hidden
         nl = len(geo.conv_dim)
         ar = dict(cap=cap)
-        ar["frames"] = self._new_act(cap["rows0"], 64)
-        ar["wave_work"] = torch.empty(lib.ser_workspace_bytes(_lib.WS_WAVE_FRAMES, cap["B"], 0, 0, 0, self.mode),
+        ar["frames"] = self._new_act(cap["rows0"], 64, stem=True)
+        ar["wave_work"] = torch.empty(lib.ser_workspace_bytes(_lib.WS_WAVE_FRAMES, cap["B"], 0, 0, 0, self.stem_mode),
                                       dtype=torch.uint8, device=dev)
-        ar["conv_act"] = [self._new_act(cap["rows0"], C0), self._new_act(cap["rows1"], C0)]       # ping-pong
+        ar["conv_act"] = [self._new_act(cap["rows0"], C0, stem=True), self._new_act(cap["rows1"], C0, stem=True)]       # ping-pong
         ar["conv_rowoff"] = [torch.empty(cap["rows1"], dtype=torch.int32, device=dev) for _ in range(1, nl)]
         ar["halo_rowmap"] = torch.empty(cap["M"], dtype=torch.int32, device=dev)
         ar["pos_rowoff"] = torch.empty(cap["M"], dtype=torch.int32, device=dev)
         ar["feat_f32"] = torch.empty((cap["M"], C0), dtype=torch.float32, device=dev)
-        ar["feat_act"] = self._new_act(cap["M"], C0)
+        ar["feat_act"] = self._new_act(cap["M"], C0, stem=True)
         ar["proj_f32"] = torch.empty((cap["M"], D), dtype=torch.float32, device=dev)
-        ar["halo_act"] = self._new_act(cap["halo"], D, zero=True, extra_rows=1)
+        ar["halo_act"] = self._new_act(cap["halo"], D, zero=True, extra_rows=1, stem=True)
         ar["states"] = torch.empty((geo.num_layers + 1, cap["M"], D), dtype=torch.float32, device=dev)
         ar["first_groups"] = 2                               # ser_row_center writes one (sum, sum^2) slot + one zero slot
         self._layer_buffers(ar, cap["M"], ar["first_groups"])
@@ -725,17 +748,17 @@ class SpeechEncoder(_EncoderBase):
         if rec is not None:
             a = rec.slot("wave_frames")
             a.wav, a.sample_offs, a.frame_offs = packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr()
-            a.B, a.k, a.stride, a.mode = B, geo.conv_kernel[0], geo.conv_stride[0], self.mode
+            a.B, a.k, a.stride, a.mode = B, geo.conv_kernel[0], geo.conv_stride[0], self.stem_mode
             a.out, a.out_plane_stride, a.work, a.total_rows = fr.ptr, fr.plane_stride, pl["wave_work"].data_ptr(), pl["rows"][0]
             rec.inputs["wav"] = a
             rec.commit(_lib.OP_WAVE_FRAMES, a, B=B, total_rows=pl["rows"][0])
         else:
             check(lib.ser_wave_frames(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr(), B,
-                                      geo.conv_kernel[0], geo.conv_stride[0], fr.ptr, fr.plane_stride, self.mode,
+                                      geo.conv_kernel[0], geo.conv_stride[0], fr.ptr, fr.plane_stride, self.stem_mode,
                                       pl["wave_work"].data_ptr(), pl["rows"][0], self._s()), "ser_wave_frames")
         a_in = pl["conv_act"][0]
         self._gemm(fr, self.conv0, pl["rows"][0], act=_lib.ACT_GELU, ln=self.conv_ln[0], ln_eps=1e-5, out_act=a_in,
-                   k_algo=geo.conv_kernel[0])
+                   k_algo=geo.conv_kernel[0], stem=True)
         # a7: conv layers 1..6 as implicit GEMMs with LayerNorm(C)+GELU fused into the epilogue
         # (the 512-wide output row lives in one block tile, so the pre-LN activations never touch HBM)
         nl = len(geo.conv_dim)
@@ -747,22 +770,22 @@ class SpeechEncoder(_EncoderBase):
                 a_view.t, a_view.rows, a_view.cols, a_view.planes = a_out.t, rows, C0, a_out.planes
                 a_view.plane_stride = a_out.plane_stride
                 self._gemm(a_in, self.convs[i - 1], rows, a_rowoff=pl["conv_rowoff"][i - 1], act=_lib.ACT_GELU,
-                           ln=self.conv_ln[i], ln_eps=1e-5, out_act=a_view)
+                           ln=self.conv_ln[i], ln_eps=1e-5, out_act=a_view, stem=True)
                 a_in = a_view
             else:
                 self._gemm(a_in, self.convs[i - 1], rows, a_rowoff=pl["conv_rowoff"][i - 1], act=_lib.ACT_GELU,
-                           ln=self.conv_ln[i], ln_eps=1e-5, out_f32=pl["feat_f32"], ldo_f32=C0)
+                           ln=self.conv_ln[i], ln_eps=1e-5, out_f32=pl["feat_f32"], ldo_f32=C0, stem=True)
         # a9: feature projection (LN -> Linear); also scatter into the zero-halo'd pos-conv input
-        self._layernorm(pl["feat_f32"], C0, self.proj_ln, M, C0, out_act=pl["feat_act"])
+        self._layernorm(pl["feat_f32"], C0, self.proj_ln, M, C0, out_act=pl["feat_act"], stem=True)
         self._gemm(pl["feat_act"], self.proj, M, out_f32=pl["proj_f32"], ldo_f32=D,
-                   out_act=pl["halo_act"], out_rowmap=pl["halo_rowmap"])
+                   out_act=pl["halo_act"], out_rowmap=pl["halo_rowmap"], stem=True)
         # a10: grouped positional conv + GELU + residual -> hidden_states[0]
         states = pl["states"]
         G, Cg, kc = geo.pos_conv_groups, self.pos_cg, self.pos_kc
         self._gemm(pl["halo_act"], self.pos, M, a_rowoff=pl["pos_rowoff"], kc=kc, ldj=D, groups=G,
                    a_group_stride=Cg, w_group_stride=Cg * geo.pos_conv_kernel * kc, c_group_stride=Cg,
                    N=Cg, K=geo.pos_conv_kernel * kc, act=_lib.ACT_GELU, residual=pl["proj_f32"], ldr=D,
-                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg)
+                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg, stem=True)
         # a11/a12: stable-LayerNorm encoder layers (LayerNorms deferred into the GEMMs)
         self._run_layers(pl, states, pl["first_groups"], B, pl["Tmax"])
 
@@ -783,8 +806,8 @@ class WhisperEncoder(_EncoderBase):
         self.mel = self._dev_f32(torch.from_numpy(whisper_mel_filters(geo.n_mels) if mel_filters is None else mel_filters))
         w1 = sd["encoder.conv1.weight"].float()
         w2 = sd["encoder.conv2.weight"].float()
-        self.conv1 = self._linear(w1.permute(0, 2, 1).reshape(D, -1), sd["encoder.conv1.bias"])
-        self.conv2 = self._linear(w2.permute(0, 2, 1).reshape(D, -1), sd["encoder.conv2.bias"])
+        self.conv1 = self._linear(w1.permute(0, 2, 1).reshape(D, -1), sd["encoder.conv1.bias"], stem=True)
+        self.conv2 = self._linear(w2.permute(0, 2, 1).reshape(D, -1), sd["encoder.conv2.bias"], stem=True)
         self.pos_emb = self._dev_f32(sd["encoder.embed_positions.weight"])
         self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
         self.layers = []
@@ -824,10 +847,10 @@ class WhisperEncoder(_EncoderBase):
         pl["offs_host"] = torch.empty(B + 1, dtype=torch.int64).pin_memory()
         pl["sample_offs"] = torch.empty(B + 1, dtype=torch.int64, device=dev)
         pl["mel"] = torch.empty((B, nm, T1), dtype=torch.float32, device=dev)
-        ws = lib.ser_workspace_bytes(_lib.WS_LOGMEL, B, 0, 0, 0, self.mode)
+        ws = lib.ser_workspace_bytes(_lib.WS_LOGMEL, B, 0, 0, 0, self.stem_mode)
         pl["work"] = torch.empty(ws, dtype=torch.uint8, device=dev)
-        pl["mel_act"] = self._new_act(B * Tp, nm)
-        pl["c1_act"] = self._new_act(B * Tp, D, zero=True)
+        pl["mel_act"] = self._new_act(B * Tp, nm, stem=True)
+        pl["c1_act"] = self._new_act(B * Tp, D, zero=True, stem=True)
         b_idx = np.repeat(np.arange(B, dtype=np.int64), T1)
         t_idx = np.tile(np.arange(T1, dtype=np.int64), B)
         pl["c1_rowoff"] = torch.tensor((b_idx * Tp + t_idx) * nm // 8, dtype=torch.int32, device=dev)
@@ -870,14 +893,14 @@ class WhisperEncoder(_EncoderBase):
             raise ValueError(f"Whisper expects input_features of shape {(B, nm, T1)}, got {tuple(input_features.shape)}")
         st = _stream()
         ma = pl["mel_act"]
-        check(lib.ser_pack_act(input_features.data_ptr(), B, nm, T1, 1, ma.ptr, nm, ma.plane_stride, self.mode, st),
+        check(lib.ser_pack_act(input_features.data_ptr(), B, nm, T1, 1, ma.ptr, nm, ma.plane_stride, self.stem_mode, st),
               "ser_pack_act")
         # stem: gelu(conv1 k3 p1), gelu(conv2 k3 s2 p1) + embed_positions -> hidden_states[0]
         self._gemm(ma, self.conv1, B * T1, a_rowoff=pl["c1_rowoff"], act=_lib.ACT_GELU, out_act=pl["c1_act"],
-                   out_rowmap=pl["c1_rowmap"])
+                   out_rowmap=pl["c1_rowmap"], stem=True)
         states = pl["states"]
         self._gemm(pl["c1_act"], self.conv2, M, a_rowoff=pl["c2_rowoff"], act=_lib.ACT_GELU, residual=self.pos_emb,
-                   ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D)
+                   ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D, stem=True)
         self._run_layers(pl, states, pl["first_groups"], B, T2)
         return HiddenStates(states, pl["frame_offs_host"])
 
@@ -892,6 +915,8 @@ class TextEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != FAMILY_ROBERTA:
             raise ValueError("TextEncoder needs a roberta geometry")
+        if mode == "f16":
+            raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
         sd = state_dict
         D = geo.hidden
         self.wemb = self._dev_f32(sd["embeddings.word_embeddings.weight"])
@@ -997,6 +1022,8 @@ class DebertaEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != "deberta":
             raise ValueError("DebertaEncoder needs a deberta geometry")
+        if mode == "f16":
+            raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
         if geo.head_dim != 64:
             raise ValueError("DeBERTa path: head dim must be 64 (K of the position GEMMs; deberta-v3 base/large have 64)")
         sd = state_dict

@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32x": 1e-3, "bf16": 3e-2}     # bf16: measured 0.6-1.5e-2 on these fixtures (round 1), gate at 2x that
+TOL = {"fp32x": 1e-3, "f16": 1e-3, "bf16": 3e-2}     # bf16: measured 0.6-1.5e-2 on these fixtures (round 1), gate at 2x that
 
 
 def synth_wave(seed, n):
@@ -32,7 +32,7 @@ def _speech_cases():
             ("tiny_hubert_d320h4", C.TINY_HUBERT)]
 
 
-@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32x", "f16", "bf16"])
 @pytest.mark.parametrize("case", [0, 1, 2])
 def test_speech_golden_ragged_batch(golden_dir, mode, case):
     """Both fixture utterances in ONE ragged batch must reproduce the per-utterance HF states."""
@@ -62,7 +62,7 @@ STRESS = [("tiny_wavlm_outlier", "wavlm"), ("tiny_hubert_outlier", "hubert"),
           ("tiny_wavlm_rowmean", "wavlm"), ("tiny_hubert_rowmean", "hubert")]
 
 
-@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32x", "f16", "bf16"])
 @pytest.mark.parametrize("case", [0, 1, 2, 3])
 def test_outlier_stress_fixtures(golden_dir, mode, case):
     """What real checkpoints do to the residual stream and Gaussian weights do not: two 1000x outlier
@@ -141,7 +141,7 @@ def test_too_short_utterance_is_rejected_cleanly():
         enc.forward(enc.upload([np.zeros(399, dtype=np.float32)]), [399])
 
 
-@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32x", "f16", "bf16"])
 def test_whisper_golden(golden_dir, mode):
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import WhisperEncoder

@@ -24,8 +24,20 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def tol(mode, bf16, fp32x):
+    """bound per numerics mode: fp16 operands (mode 3) round 8x finer than bf16; gate at 1/5 of the bf16 bound."""
+    return {1: bf16, 2: fp32x, 3: max(bf16 / 5, fp32x)}[mode]
+
+
+def act_dtype(mode):
+    return torch.float16 if mode == 3 else torch.bfloat16
+
+
 def to_act(x, mode):
-    """fp32 CPU [rows, cols] -> device bf16 planes the way ser_split_bf16 does (host restatement)."""
+    """fp32 CPU [rows, cols] -> device operand planes the way ser_split_bf16 does (host restatement):
+    mode 1 = one bf16 plane, 2 = bf16 hi + lo, 3 = one fp16 plane."""
+    if mode == 3:
+        return x.to(torch.float16)[None].contiguous().to(DEV)
     hi = x.to(torch.bfloat16)
     if mode == 1:
         return hi[None].contiguous().to(DEV)
@@ -64,7 +76,7 @@ def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
     planes = 2 if mode == 2 else 1
     out_act = None
     if kw.get("want_act", False):
-        out_act = torch.zeros((planes, kw.get("out_act_rows", M), ncols), dtype=torch.bfloat16, device=DEV)
+        out_act = torch.zeros((planes, kw.get("out_act_rows", M), ncols), dtype=act_dtype(mode), device=DEV)
         g.out_act = out_act.data_ptr()
         g.ldo_act = ncols
         g.out_plane_stride = out_act.shape[1] * ncols
@@ -79,17 +91,19 @@ def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
         g.stat_out, g.stat_groups = kw["stat_out"].data_ptr(), kw["stat_out"].shape[1]
     g.tile_cfg = kw.get("tile_cfg", 0)
     if kw.get("shift_out") is not None:
-        rs, si = kw.get("shift_stats"), kw.get("shift_in")
-        g.shift_stats, g.shift_groups = (rs.data_ptr(), rs.shape[1]) if rs is not None else (None, 0)
-        g.shift_cols = kw.get("shift_cols", N)
+        si = kw.get("shift_in")
         g.shift_in = si.data_ptr() if si is not None else None
         g.shift_out, g.shift_const = kw["shift_out"].data_ptr(), kw.get("shift_const", 0.0)
+    if kw.get("mean_out") is not None:
+        ls = kw.get("ln_shift")
+        g.ln_shift = ls.data_ptr() if ls is not None else None
+        g.mean_out = kw["mean_out"].data_ptr()
     L.check(L.lib.ser_gemm(C.byref(g), stream()), "ser_gemm")
     torch.cuda.synchronize()
     return out_f32, out_act
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (77, 8, 64), (515, 392, 1024)])
 def test_gemm_integer_exact(L, mode, M, N, K):
     """Small-integer operands are exact in bf16 and fp32: any layout / swizzle / permutation slip
@@ -102,7 +116,7 @@ def test_gemm_integer_exact(L, mode, M, N, K):
     assert torch.equal(out.cpu().double(), ref)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 256), (257, 264, 64), (1030, 128, 640), (300, 136, 128), (140, 256, 192), (129, 8, 320)])
 def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
@@ -117,7 +131,7 @@ def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
     assert torch.equal(out.cpu().double(), ref)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K,bias", [(300, 512, 192, True), (1000, 512, 1536, False), (77, 64, 128, True),
                                         (13001, 512, 128, True), (25999, 512, 64, False)])
 def test_gemm_layernorm_gelu_epilogue(L, mode, M, N, K, bias):
@@ -138,10 +152,10 @@ def test_gemm_layernorm_gelu_epilogue(L, mode, M, N, K, bias):
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 2e-4, err
     err_act = (act_value(oact).cpu().double() - ref).abs().max().item()
-    assert err_act < (4e-2 if mode == 1 else 3e-4), err_act
+    assert err_act < tol(mode, 4e-2, 3e-4), err_act
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [1, 3])
 def test_gemm_row_stats_and_deferred_layernorm(L, mode, cfg):
     """Producer GEMM writes x (fp32 + act) and per-64-column (sum, sum^2) partials; the consumer GEMM
@@ -169,10 +183,10 @@ def test_gemm_row_stats_and_deferred_layernorm(L, mode, cfg):
     t = (W.double() @ beta.double() + b.double()).float().to(DEV)
     out, _ = run_gemm(L, x_act, Wp, M, N2, D, mode, bias=t, ln_stats=stat, ln_groups=G, ln_colsum=colsum, tile_cfg=cfg)
     err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    assert err < (3e-2 if mode == 1 else 5e-5), err
+    assert err < tol(mode, 3e-2, 5e-5), err
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [1, 2])
 def test_shifted_operand_chain_large_row_mean(L, mode, cfg):
     """Rows whose mean is ~50 standard deviations (an offset living in the residual stream): ser_row_center gives the
@@ -192,7 +206,7 @@ def test_shifted_operand_chain_large_row_mean(L, mode, cfg):
     mean0 = x0.double().mean(1)
     assert (sh0.cpu().double() - mean0).abs().max() < 1e-4
     cen = x0.double() - sh0.cpu().double()[:, None]
-    assert (act_value(x0_act).cpu().double() - cen).abs().max() < (2e-2 if mode == 1 else 2e-4)
+    assert (act_value(x0_act).cpu().double() - cen).abs().max() < tol(mode, 2e-2, 2e-4)
     assert (st0.cpu().double()[:, 0, 1] - (cen * cen).sum(1)).abs().max() < 1e-2 and float(st0[:, 1].abs().max()) == 0.0
     # producer: x1 = x0 + A W^T + b, b carries a uniform +3
     A0 = torch.randn(M, 128, generator=g)
@@ -203,13 +217,13 @@ def test_shifted_operand_chain_large_row_mean(L, mode, cfg):
     stat = torch.zeros(M, G, 2, device=DEV)
     sh1 = torch.zeros(M, device=DEV)
     x1_f32, x1_act = run_gemm(L, to_act(A0, mode), to_act(W0, mode), M, D, 128, mode, bias=b0.to(DEV), residual=x0.to(DEV), ldr=D,
-                              want_act=True, stat_out=stat, tile_cfg=cfg, shift_stats=st0, shift_in=sh0, shift_out=sh1,
-                              shift_const=float(b0.double().mean()), shift_cols=D)
+                              want_act=True, stat_out=stat, tile_cfg=cfg, shift_in=sh0, shift_out=sh1,
+                              shift_const=float(b0.double().mean()))
     x1 = x1_f32.cpu().double()
     c1 = sh1.cpu().double()
     assert (c1 - (mean0 + b0.double().mean())).abs().max() < 1e-3               # shift = mean(residual row) + mean(bias)
     assert (x1.mean(1) - c1).abs().max() < 1.0                                    # ... which tracks the true row mean
-    assert (act_value(x1_act).cpu().double() - (x1 - c1[:, None])).abs().max() < (3e-2 if mode == 1 else 3e-4)
+    assert (act_value(x1_act).cpu().double() - (x1 - c1[:, None])).abs().max() < tol(mode, 3e-2, 3e-4)
     ssum = stat.cpu().double().sum(1)
     assert (ssum[:, 0] - (x1 - c1[:, None]).sum(1)).abs().max() < 1e-2
     # consumer: LayerNorm(x1) W^T + b from the shifted copy and its partials
@@ -221,9 +235,12 @@ def test_shifted_operand_chain_large_row_mean(L, mode, cfg):
     Wp = to_act((W.double() * gamma.double()[None, :]).float(), mode)
     colsum = act_value(Wp).double().sum(1).float().contiguous()
     t = (W.double() @ beta.double() + b.double()).float().to(DEV)
-    out, _ = run_gemm(L, x1_act, Wp, M, N2, D, mode, bias=t, ln_stats=stat, ln_groups=G, ln_colsum=colsum, tile_cfg=cfg)
+    m1 = torch.full((M,), float("nan"), device=DEV)
+    out, _ = run_gemm(L, x1_act, Wp, M, N2, D, mode, bias=t, ln_stats=stat, ln_groups=G, ln_colsum=colsum, tile_cfg=cfg,
+                      ln_shift=sh1, mean_out=m1)
     err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    assert err < (3e-2 if mode == 1 else 1e-4), err
+    assert err < tol(mode, 3e-2, 1e-4), err
+    assert (m1.cpu().double() - x1.mean(1)).abs().max() < 1e-3                  # the consumer reports the absolute row mean
 
 
 @pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 2e-5)])
@@ -241,7 +258,7 @@ def test_gemm_epilogue_and_precision(L, mode, tol):
     assert err < tol, err
     # the act output is the same value, re-split
     err_act = (act_value(oact).cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    assert err_act < (1e-2 if mode == 1 else 5e-5), err_act
+    assert err_act < tol(mode, 1e-2, 5e-5), err_act
 
 
 def test_gemm_fp32x_beats_bf16(L):
@@ -256,7 +273,7 @@ def test_gemm_fp32x_beats_bf16(L):
     assert e[2] < 2e-5 and e[2] * 50 < e[1], e
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_gemm_conv_rowmap(L, mode):
     """Strided Conv1d (k=3, stride 2) over channels-last rows of two packed utterances."""
     Cin, Cout, k, s = 64, 72, 3, 2
@@ -278,7 +295,7 @@ def test_gemm_conv_rowmap(L, mode):
     assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("Cg", [64, 80, 120])
 def test_gemm_grouped_posconv(L, mode, Cg):
     """Grouped conv (k=128, pad 64, drop last frame) through the kc/ldj map with channel padding
@@ -313,7 +330,7 @@ def test_gemm_grouped_posconv(L, mode, Cg):
                       a_rowoff=torch.tensor(ro, dtype=torch.int32, device=DEV), kc=kc, ldj=D, groups=G, ags=Cg,
                       wgs=Cg * k * kc, cgs=Cg, bias=bias.to(DEV), act=1, residual=x.to(DEV), ldr=D)
     err = (out.cpu().double() - ref).abs().max().item()
-    assert err < (2e-3 if mode == 1 else 3e-5), err
+    assert err < tol(mode, 2e-3, 3e-5), err
 
 
 def test_gemm_rowmap_and_rowmod(L):
@@ -356,7 +373,7 @@ def test_layernorm(L, mode, D, gelu):
                                 oa.data_ptr(), D, rows * D, mode, rows, D, stream()))
     torch.cuda.synchronize()
     assert (of.cpu().double() - ref).abs().max().item() < 2e-5
-    assert (act_value(oa).cpu().double() - ref).abs().max().item() < (4e-2 if mode == 1 else 1e-4)
+    assert (act_value(oa).cpu().double() - ref).abs().max().item() < tol(mode, 4e-2, 1e-4)
 
 
 def test_wave_norm(L):
@@ -405,7 +422,7 @@ def test_conv0_ln_gelu(L, mode, Cc, bias):
                                     sum(T) * Cc, mode, Cc, k, s, sum(T), stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
-    assert err < (4e-2 if mode == 1 else 2e-4), err
+    assert err < tol(mode, 4e-2, 2e-4), err
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -431,7 +448,7 @@ def test_wave_frames_feeds_matrix_core_conv0(L, mode):
     for b, w in enumerate(waves):
         xn = (w - w.mean()) / np.sqrt(w.var() + 1e-7)                      # HF zero_mean_unit_var_norm
         ref = np.stack([xn[s * t: s * t + k] for t in range(T[b])])
-        assert np.abs(fv[o:o + T[b], :k].numpy() - ref).max() < (2e-2 if mode == 1 else 3e-5)
+        assert np.abs(fv[o:o + T[b], :k].numpy() - ref).max() < tol(mode, 2e-2, 3e-5)
         assert torch.count_nonzero(fv[o:o + T[b], k:]) == 0
         o += T[b]
     g = torch.Generator().manual_seed(0)
@@ -444,7 +461,7 @@ def test_wave_frames_feeds_matrix_core_conv0(L, mode):
     ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(pre, (Cc,), lw.double(), lb.double(), 1e-5))
     _, oact = run_gemm(L, frames, Wa, rows, Cc, 64, mode, act=1, ln=(lw.to(DEV), lb.to(DEV)), want_act=True, want_f32=False)
     err = (act_value(oact).cpu().double() - ref).abs().max().item()
-    assert err < (4e-2 if mode == 1 else 3e-4), err
+    assert err < tol(mode, 4e-2, 3e-4), err
 
 
 def test_bias_table_bit_exact(L, golden_dir):
@@ -489,7 +506,7 @@ def attention_reference(q, k, v, scale, table=None, gate=None):
     return torch.matmul(torch.softmax(s, dim=-1), v)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("dh,H,bias", [(64, 2, True), (64, 3, False), (80, 2, False), (120, 2, False), (128, 1, False)])
 def test_attention(L, mode, dh, H, bias):
     Ts = [70, 129, 5, 200]
@@ -518,7 +535,7 @@ def test_attention(L, mode, dh, H, bias):
         o = attention_reference(q, k, v, dh ** -0.5, tb, gt)
         ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
     planes = 2 if mode == 2 else 1
-    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
     foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
     td = table.to(DEV) if bias else None
     gd = gate.to(DEV) if bias else None
@@ -527,10 +544,10 @@ def test_attention(L, mode, dh, H, bias):
                                 out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, None, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
-    assert err < (3e-2 if mode == 1 else 1e-4), err
+    assert err < tol(mode, 3e-2, 1e-4), err
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_attention_fused_gate_columns(L, mode):
     """WavLM gate from its two pre-activation columns per head inside the packed projection matrix."""
     Ts, H, dh = [90, 200], 2, 64
@@ -556,14 +573,14 @@ def test_attention_fused_gate_columns(L, mode):
         o = attention_reference(q, k, v, dh ** -0.5, table[:, c - (T - 1): c + T].double(), gate[offs[b]:offs[b + 1]])
         ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
     planes = 2 if mode == 2 else 1
-    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
     foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
     td, cd = table.to(DEV), cst.to(DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), ld, M * ld, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax, td.data_ptr(), Tmax,
                                 None, out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 3 * D, cd.data_ptr(), None, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
-    assert err < (3e-2 if mode == 1 else 1e-4), err
+    assert err < tol(mode, 3e-2, 1e-4), err
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -594,7 +611,7 @@ def test_attention_prescaled_q(L, mode, dh, bias):
                                 gate[offs[b]:offs[b + 1]].double() if bias else None)
         ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
     planes = 2 if mode == 2 else 1
-    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
     foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
     td = table.to(DEV) if bias else None
     gd = gate.to(DEV) if bias else None
@@ -603,7 +620,7 @@ def test_attention_prescaled_q(L, mode, dh, bias):
                                 out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, None, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
-    assert err < (3e-2 if mode == 1 else 1e-4), err
+    assert err < tol(mode, 3e-2, 1e-4), err
 
 
 def test_gemm_column_scale(L):
@@ -642,14 +659,14 @@ def test_attention_key_lengths(L, mode):
         s[:, :, klens[b]:] = float("-inf")
         ref[b * T:(b + 1) * T] = torch.matmul(torch.softmax(s, -1), v).permute(1, 0, 2).reshape(T, D)
     planes = 2 if mode == 2 else 1
-    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
     foffs = torch.arange(0, M + 1, T, dtype=torch.int32, device=DEV)
     kl = torch.tensor(klens, dtype=torch.int32, device=DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), B, T, None, 0, None,
                                 out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, kl.data_ptr(), stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
-    assert err < (3e-2 if mode == 1 else 1e-4), err
+    assert err < tol(mode, 3e-2, 1e-4), err
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -673,7 +690,7 @@ def test_embed_ln(L, mode):
                                1e-5, of.data_ptr(), oa.data_ptr(), B * T * D, mode, B, T, D, pad, stream()))
     torch.cuda.synchronize()
     assert (of.cpu().double() - ref).abs().max().item() < 2e-5
-    assert (act_value(oa).cpu().double() - ref).abs().max().item() < (4e-2 if mode == 1 else 1e-4)
+    assert (act_value(oa).cpu().double() - ref).abs().max().item() < tol(mode, 4e-2, 1e-4)
 
 
 def test_attention_online_softmax_rescale(L):
