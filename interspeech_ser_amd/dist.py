@@ -68,7 +68,10 @@ def _comm_device() -> torch.device:
 
 def broadcast_state_dict(sd: Optional[StateDict], src: int = 0) -> Tuple[StateDict, float, int]:
     """C1.  ``sd`` is the real state dict on rank ``src`` and may be None elsewhere.
-    Returns (state dict of CPU fp32 tensors, seconds spent in the broadcast, bytes)."""
+    Returns (state dict of fp32 tensors, seconds spent in the broadcast, bytes).  The tensors are VIEWS of the one
+    flat bucket that was broadcast and stay where the collective left them -- in HBM on the "nccl" (RCCL) backend,
+    on every rank including ``src`` -- so the weights cross xGMI once and never bounce through host memory; the
+    encoder constructors fold / split them on the device."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         assert sd is not None
         return sd, 0.0, 0
@@ -90,14 +93,13 @@ def broadcast_state_dict(sd: Optional[StateDict], src: int = 0) -> Tuple[StateDi
     if dev.type == "cuda":
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if rank == src:
-        return sd, dt, total * 4
-    flat = flat.cpu()
+    if rank == src and dev.type == "cpu":
+        return sd, dt, total * 4                   # gloo: rank src already holds CPU tensors
     out: StateDict = {}
     o = 0
     for k, shape in entries:
         n = int(torch.Size(shape).numel())
-        out[k] = flat[o:o + n].view(shape).clone()
+        out[k] = flat[o:o + n].view(shape)         # no copy: a view into the bucket
         o += n
     return out, dt, total * 4
 

@@ -391,7 +391,8 @@ class _EncoderBase:
     def _layer_weights(self, sd, p: str, a: str, ln1: str, ln2: str, fc1: str, fc2: str, k_bias: bool, gate: bool):
         """One encoder layer's GEMM operands; LN1 folds into the packed QKV (+gate) projection, LN2 into FC1."""
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
-        kb = sd[a + ".k_proj.bias"] if k_bias else torch.zeros(D)
+        wdev = sd[a + ".q_proj.weight"].device            # CPU state dict, or device views of the broadcast bucket (dist.py)
+        kb = sd[a + ".k_proj.bias"] if k_bias else torch.zeros(D, device=wdev)
         ws = [sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]]
         bs = [sd[a + ".q_proj.bias"], kb, sd[a + ".v_proj.bias"]]
         lay = {}
@@ -400,13 +401,13 @@ class _EncoderBase:
             # LN1(x) -> 2H extra output columns of the packed projection; the gate kernel disappears
             w8, b8 = sd[a + ".gru_rel_pos_linear.weight"].float(), sd[a + ".gru_rel_pos_linear.bias"].float()
             wa, wb = w8[:4].sum(0), w8[4:].sum(0)
-            wg = torch.zeros(2 * H, D)
+            wg = torch.zeros(2 * H, D, device=wdev)
             for h in range(H):
                 wg[2 * h, h * dh:(h + 1) * dh] = wa
                 wg[2 * h + 1, h * dh:(h + 1) * dh] = wb
             pad = (-2 * H) % 8                                   # GEMM N must stay a multiple of 8
-            ws.append(torch.cat([wg, torch.zeros(pad, D)], 0))
-            bs.append(torch.cat([torch.stack([b8[:4].sum(), b8[4:].sum()]).repeat(H), torch.zeros(pad)]))
+            ws.append(torch.cat([wg, torch.zeros(pad, D, device=wdev)], 0))
+            bs.append(torch.cat([torch.stack([b8[:4].sum(), b8[4:].sum()]).repeat(H), torch.zeros(pad, device=wdev)]))
             lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
         lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"])
         lay["out"] = self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"])

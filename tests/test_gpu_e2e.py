@@ -405,3 +405,29 @@ def test_command_list_replay_equals_launch_by_launch():
         assert a.frame_offs == b.frame_offs
         assert torch.equal(a.states, b.states), k
     assert taped._arenas[0].get("tape") is not None and eager._arenas[0].get("tape") is None
+
+
+@pytest.mark.parametrize("family", ["wavlm", "hubert", "whisper"])
+def test_encoder_from_device_resident_weights(family):
+    """dist.broadcast_state_dict leaves the broadcast weights in HBM (views of the one RCCL bucket): an encoder built
+    from device-resident tensors must equal the one built from the CPU state dict of a single-rank run."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import build_encoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = {"wavlm": C.TINY_WAVLM, "hubert": C.TINY_HUBERT, "whisper": C.TINY_WHISPER}[family]
+    sd = synthetic_state_dict(geo, 9)
+    flat = torch.cat([sd[k].reshape(-1) for k in sorted(sd)]).to("cuda:0")            # what the collective leaves behind
+    sd_dev, o = {}, 0
+    for k in sorted(sd):
+        n = sd[k].numel()
+        sd_dev[k] = flat[o:o + n].view(sd[k].shape)
+        o += n
+    waves = [synth_wave(3, 20000), synth_wave(4, 9000)]
+    lens = [len(w) for w in waves]
+    outs = []
+    for weights in (sd, sd_dev):
+        enc = build_encoder(geo, weights, "cuda:0", "fp32x")
+        hs = enc.forward(enc.upload(waves), lens)
+        torch.cuda.synchronize()
+        outs.append(hs.states.clone())
+    assert rel_err(outs[1], outs[0]) < 1e-6
