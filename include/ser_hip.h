@@ -298,6 +298,16 @@ typedef struct ser_cmd {
  * (ser_last_error() names it); *failed_at, if not NULL, receives the index. */
 int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void* stream);
 
+/* ---- host-side file I/O (HOST pointers, no stream; plain C, re-entrant, entered without the Python GIL) --------------
+ * a5  ser_wav_read_f32: what librosa.load(path, sr=16000) -> soundfile yields for a RIFF/WAVE file
+ *     (preprocessing/preprocess_speech.py:47) before any resampling: mono float32 in [-1, 1], integer PCM / 2^(bits-1),
+ *     channels averaged.  Returns the number of frames, or < 0; with host_dst == NULL only the header is read.
+ * a21 ser_pt_write_f32: the file torch.save(feats, "<name>.pt") leaves for the heads (preprocess_speech.py:69-71;
+ *     consumer torch.load(path), bin/train_cat_bimodal_lazy_1head.py:227): a bare [rows, cols] float32 CPU tensor in
+ *     torch's zip archive format. */
+int64_t ser_wav_read_f32(const char* path, float* host_dst, int64_t capacity, int32_t* sample_rate, int32_t* channels);
+int     ser_pt_write_f32(const char* path, const float* host_data, int64_t rows, int64_t cols);
+
 #define SER_WS_LOGMEL 1
 #define SER_WS_WAVE_FRAMES 2
 size_t ser_workspace_bytes(int op, int B, int T, int D, int H, int mode);

@@ -135,6 +135,8 @@ _SIGNATURES = {
     "ser_run": (c_int, [c_void_p, C.c_int32, c_void_p, c_void_p]),
     "ser_ragged_index": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64, c_void_p]),
     "ser_workspace_bytes": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ser_wav_read_f32": (c_i64, [C.c_char_p, c_void_p, c_i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ser_pt_write_f32": (c_int, [C.c_char_p, c_void_p, c_i64, c_i64]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -23,6 +23,23 @@ class UnsupportedAudio(ValueError):
     pass
 
 
+def _native_wav(path: str):
+    """RIFF/WAVE through libserhip's ser_wav_read_f32 (plain C, runs without the GIL): (samples, rate) or None when
+    the file is not something that reader handles (the Python decoder below then gives the verdict)."""
+    import ctypes
+    from ._lib import lib
+    sr, ch = ctypes.c_int32(0), ctypes.c_int32(0)
+    bpath = os.fsencode(path)
+    n = lib.ser_wav_read_f32(bpath, None, 0, ctypes.byref(sr), ctypes.byref(ch))
+    if n < 0:
+        return None
+    x = np.empty(int(n), dtype=np.float32)
+    got = lib.ser_wav_read_f32(bpath, x.ctypes.data, int(n), None, None)
+    if got != n:
+        return None
+    return x, int(sr.value)
+
+
 def load_wav_16k(path: str, resample: bool = False) -> np.ndarray:
     """Decode a RIFF/WAVE file to mono float32 in [-1, 1] the way soundfile (behind
     ``librosa.load``) does: integer PCM / 2^(bits-1), channels averaged.
@@ -30,7 +47,11 @@ def load_wav_16k(path: str, resample: bool = False) -> np.ndarray:
     (librosa 0.10.1), which is not available offline and not restated -- by default such
     files raise and the driver logs "Failed to process" like any other per-file error; with
     ``resample=True`` (driver flag ``--resample``) they go through a Kaiser-windowed polyphase filter
-    (``scipy.signal.resample_poly``): usable features, but PARITY UNPINNED against the reference's resampler."""
+    (``scipy.signal.resample_poly``): usable features, but PARITY UNPINNED against the reference's resampler.
+    16 kHz files take the native reader (same arithmetic, no GIL); everything else the Python path below."""
+    native = _native_wav(path)
+    if native is not None and native[1] == TARGET_SR:
+        return native[0]
     try:
         with _wave.open(path, "rb") as wf:
             sr, ch, width, n = wf.getframerate(), wf.getnchannels(), wf.getsampwidth(), wf.getnframes()
@@ -111,4 +132,11 @@ def save_feature(feats: torch.Tensor, path: str) -> None:
     t = feats.detach()
     if t.device.type != "cpu":
         t = t.cpu()
-    torch.save(t.to(torch.float32).contiguous().clone(), path)
+    t = t.to(torch.float32).contiguous()
+    if t.dim() == 2 and t.shape[1] > 0:
+        # same archive torch.save writes, produced by libserhip's ser_pt_write_f32 without the GIL: the writer threads
+        # of the driver no longer serialise on the interpreter (pickler + Python zip bookkeeping of torch.save)
+        from ._lib import check, lib
+        check(lib.ser_pt_write_f32(os.fsencode(path), t.data_ptr(), t.shape[0], t.shape[1]), "ser_pt_write_f32")
+        return
+    torch.save(t.clone(), path)

@@ -197,7 +197,7 @@ def test_shifted_operand_chain_large_row_mean(L, mode, cfg):
     g = torch.Generator().manual_seed(5 + cfg)
     x0 = torch.randn(M, D, generator=g) + 50.0 + torch.randn(M, 1, generator=g) * 20
     planes = 2 if mode == 2 else 1
-    x0_act = torch.zeros((planes, M, D), dtype=torch.bfloat16, device=DEV)
+    x0_act = torch.zeros((planes, M, D), dtype=act_dtype(mode), device=DEV)
     st0 = torch.full((M, 2, 2), float("nan"), device=DEV)
     sh0 = torch.zeros(M, device=DEV)
     L.check(L.lib.ser_row_center(x0.to(DEV).data_ptr(), D, x0_act.data_ptr(), D, M * D, st0.data_ptr(), 2, sh0.data_ptr(),
