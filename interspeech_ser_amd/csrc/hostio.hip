@@ -182,14 +182,16 @@ std::string pickle_f32_matrix(int64_t rows, int64_t cols) {
         s.push_back('J');
         for (int i = 0; i < 4; ++i) s.push_back((char)((v >> (8 * i)) & 0xff));
     };
-    std::string p("\x80\x02" "ctorch._utils\n_rebuild_tensor_v2\nq\x00((X\x07\x00\x00\x00storageq\x01"
-                  "ctorch\nFloatStorage\nq\x02X\x01\x00\x00\x00" "0q\x03X\x03\x00\x00\x00" "cpuq\x04", 91);
+#define SER_LIT(x) std::string(x, sizeof(x) - 1)                       /* literals with embedded NULs */
+    std::string p = SER_LIT("\x80\x02" "ctorch._utils\n_rebuild_tensor_v2\nq\x00((X\x07\x00\x00\x00storageq\x01"
+                            "ctorch\nFloatStorage\nq\x02X\x01\x00\x00\x00" "0q\x03X\x03\x00\x00\x00" "cpuq\x04");
     J(p, rows * cols);
-    p += std::string("tq\x05QK\x00", 6);
+    p += SER_LIT("tq\x05QK\x00");
     J(p, rows); J(p, cols);
-    p += std::string("\x86q\x06", 3);
+    p += SER_LIT("\x86q\x06");
     J(p, cols);
-    p += std::string("K\x01\x86q\x07\x89" "ccollections\nOrderedDict\nq\x08)Rq\x09tq\x0aRq\x0b.", 46);
+    p += SER_LIT("K\x01\x86q\x07\x89" "ccollections\nOrderedDict\nq\x08)Rq\x09tq\x0aRq\x0b.");
+#undef SER_LIT
     return p;
 }
 
