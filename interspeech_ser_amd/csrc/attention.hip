@@ -96,7 +96,13 @@ void attention_kernel(const AttnParams p) {
     const int hh = lane >> 5, l31 = lane & 31;
     const int TK = p.key_lens ? p.key_lens[b] : T;               // attendable keys (== T for speech)
     const int nkt = (TK + ABKV - 1) / ABKV;
-    const int jmin = max(0, (T - 1) - (q0 + 32 * NWV - 1));         // first relative-position slot any query of this block reads
+    // first relative-position slot any query of this block reads, moved down by 0..3 (possibly below 0: zero-filled) so
+    // that T-1-jmin == 3 (mod 4).  Queries 4m..4m+3 of a quad then read the SAME aligned offset of the 4 shifted copies
+    // (one 16-lane group of a ds_read_b128 = 4 quads x 4 copies = 16 distinct 4-bank slots); with any other residue a
+    // quad straddles two offsets and two of its lanes collide with the neighbouring quad (the q-tile holding the
+    // utterance's last query used to run like that: 498 = 2 mod 4 at T = 499).
+    const int jmin0 = max(0, (T - 1) - (q0 + 32 * NWV - 1));
+    const int jmin = jmin0 - ((3 - (T - 1 - jmin0)) & 3);
 
     // ---- staging helpers: thread owns chunks c = tid + i*256 of the [64 keys][CPR] tile --------
     u32x4 stg[NP][2][NCH];
@@ -177,14 +183,14 @@ void attention_kernel(const AttnParams p) {
         // each table element is read ONCE (5 independent loads in flight per thread and pass) and
         // scattered into the 4 shifted copies; indices past 2T-1 are written as zeros (tail padding)
         // only the distances this block's queries can see: key - query + T-1 in [jmin, jmin + 32*NWV + T + 63]
-        const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T) + jmin;
+        const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T) + jmin;     // jmin may be -3..-1: guarded below
         const int n = 2 * T - 1 - jmin, span = p.bias_stride + 3;
         for (int base = 0; base < span; base += 5 * NT) {
             float v[5];
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
                 const int idx = base + u * NT + tid;
-                v[u] = idx < n ? trow[idx] : 0.f;
+                v[u] = (idx < n && idx + jmin >= 0) ? trow[idx] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
@@ -470,7 +476,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     // lane group then land on 16 distinct 4-bank slots (a multiple of 64 made them 2-way conflicts)
     int bias_stride = 0;
     if (table) {
-        bias_stride = ((max_frames + 32 * nwv + 2 * ABKV + 3) / 4) * 4;       // window of one query block, not all 2T-1 distances
+        bias_stride = ((max_frames + 32 * nwv + 2 * ABKV + 3 + 4) / 4) * 4;   // window of one query block (+ the 0..3 alignment slots), not all 2T-1 distances
         bias_stride += (16 - (bias_stride & 63) + 64) & 63;
     }
     const size_t lds = (size_t)nbuf * 2 * np * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;

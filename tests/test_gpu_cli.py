@@ -103,7 +103,7 @@ def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
     utterances, written by the two drivers, read back the way the bimodal head's dataset / collate / forward do."""
     import pandas as pd
     from interspeech_ser_amd import driver
-    from test_consumer_contract import _Head, _collate, _item
+    from oracle import fusion_head as H          # the reference head, restated and pinned (tests/test_consumer_contract.py)
     wav_dir, d1, d2 = tmp_path / "Audios", tmp_path / "hubert", tmp_path / "roberta"
     wav_dir.mkdir()
     names = [f"MSP_{i:03d}.wav" for i in range(4)]
@@ -128,8 +128,15 @@ def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
                                "--synthetic_weights", "--mode", "bf16"], tokenize=tok) == 0
     assert sorted(os.listdir(d1)) == sorted(os.listdir(d2)) == [n.replace(".wav", ".pt") for n in names]
     labels = np.eye(8, dtype=np.float32)[[0, 3, 5, 7]]
-    batch = _collate([_item(n, str(d1), str(d2), lab) for n, lab in zip(names, labels)])
+    batch = H.collate_fn([H.dataset_item(n, str(d1), str(d2), lab) for n, lab in zip(names, labels)])
     assert batch["feat1"].shape[0] == 4 and batch["feat1"].shape[2] == 1280 and batch["feat2"].shape == (4, 80, 1024)
+    # the reference head at its real size (Linear(1280,512) / Linear(1024,512) -> biGRU(512) -> cross-MHA(1024) -> 8), seeded
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fusion_head_pins.npz"))
+    shapes = {str(k): tuple(int(x) for x in str(sh).split(",")) for k, sh in zip(g["keys"], g["shapes"])}
+    head = H.MultiModalEmotionClassifier(1280, 1024, 512, 8, 0.5).eval()
+    head.load_state_dict(H.seeded_head_weights(shapes, int(g["seed_weights"])), strict=True)
     with torch.no_grad():
-        logits = _Head(1280, 1024).eval()(batch["feat1"], batch["feat2"])
+        logits = head(batch["feat1"], batch["feat2"])
     assert logits.shape == (4, 8) and torch.isfinite(logits).all()
+    loss = torch.nn.CrossEntropyLoss()(logits, batch["label"].max(dim=1)[1].long())
+    assert torch.isfinite(loss)
