@@ -145,6 +145,18 @@ def wavlm_gate(geo, sd: StateDict, prefix: str, x_ln: Tensor) -> Tensor:
     return a * (b * const - 1.0) + 2.0
 
 
+def _proj(sd: StateDict, name: str, x: Tensor, bias: bool = True) -> Tensor:
+    """nn.Linear, or -- when the state dict carries ``<name>.lora_A.weight`` [r, in] / ``<name>.lora_B.weight`` [out, r]
+    and ``lora_scale`` -- a PEFT LoRA Linear in eval mode, applied UN-MERGED as the wrapped module computes it:
+    ``x W^T + b + (alpha / r) * (x A^T) B^T``  (peft.tuners.lora.Linear.forward; the reference wraps q_proj / v_proj with
+    r = 8, alpha = 16: preprocessing/preprocess_speech_pretrained.py:119-130, extracts with ``ssl_model.wavlm.model``
+    :170-172).  This is what pins the product's load-time merge (weights.merge_lora)."""
+    y = F.linear(x, sd[name + ".weight"], sd[name + ".bias"] if bias else None)
+    if name + ".lora_A.weight" in sd:
+        y = y + float(sd["lora_scale"]) * F.linear(F.linear(x, sd[name + ".lora_A.weight"]), sd[name + ".lora_B.weight"])
+    return y
+
+
 def _heads(x: Tensor, H: int) -> Tensor:
     T, D = x.shape
     return x.view(T, H, D // H).permute(1, 0, 2)                           # [H, T, dh]
@@ -155,9 +167,9 @@ def wavlm_attention(geo, sd: StateDict, prefix: str, x_ln: Tensor, bias_table: T
     (HF modeling_wavlm.py:147-241 via F.multi_head_attention_forward)."""
     T = x_ln.shape[0]
     H, dh = geo.heads, geo.head_dim
-    q = _heads(F.linear(x_ln, sd[prefix + ".q_proj.weight"], sd[prefix + ".q_proj.bias"]), H)
-    k = _heads(F.linear(x_ln, sd[prefix + ".k_proj.weight"], sd[prefix + ".k_proj.bias"]), H)
-    v = _heads(F.linear(x_ln, sd[prefix + ".v_proj.weight"], sd[prefix + ".v_proj.bias"]), H)
+    q = _heads(_proj(sd, prefix + ".q_proj", x_ln), H)
+    k = _heads(_proj(sd, prefix + ".k_proj", x_ln), H)
+    v = _heads(_proj(sd, prefix + ".v_proj", x_ln), H)
     idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None]) + (T - 1)  # [q, k]
     bias = bias_table[:, idx]                                               # [H, T, T]
     gate = wavlm_gate(geo, sd, prefix, x_ln)                                # [H, T]
@@ -173,9 +185,9 @@ def plain_attention(geo, sd: StateDict, prefix: str, x_ln: Tensor, *, k_bias: bo
     Whisper scales q before the product and has no k bias, modeling_whisper.py:279-357)."""
     T = x_ln.shape[0]
     H, dh = geo.heads, geo.head_dim
-    q = _heads(F.linear(x_ln, sd[prefix + ".q_proj.weight"], sd[prefix + ".q_proj.bias"]), H)
-    k = _heads(F.linear(x_ln, sd[prefix + ".k_proj.weight"], sd[prefix + ".k_proj.bias"] if k_bias else None), H)
-    v = _heads(F.linear(x_ln, sd[prefix + ".v_proj.weight"], sd[prefix + ".v_proj.bias"]), H)
+    q = _heads(_proj(sd, prefix + ".q_proj", x_ln), H)
+    k = _heads(_proj(sd, prefix + ".k_proj", x_ln, bias=k_bias), H)
+    v = _heads(_proj(sd, prefix + ".v_proj", x_ln), H)
     scores = torch.matmul(q * (dh ** -0.5), k.transpose(1, 2))
     ctx = torch.matmul(torch.softmax(scores, dim=-1), v)
     ctx = ctx.permute(1, 0, 2).reshape(T, H * dh)

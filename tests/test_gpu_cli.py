@@ -140,3 +140,65 @@ def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
     assert logits.shape == (4, 8) and torch.isfinite(logits).all()
     loss = torch.nn.CrossEntropyLoss()(logits, batch["label"].max(dim=1)[1].long())
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("family", ["wavlm", "hubert"])
+def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, capsys, family):
+    """Next row 8f-4 end to end (preprocessing/preprocess_speech_pretrained.py:108-177): a PEFT-wrapped checkpoint --
+    ``wavlm.base_model.model.*`` names, ``q_proj`` / ``v_proj`` split into ``base_layer`` + ``lora_A`` / ``lora_B`` (r = 8,
+    alpha = 16), a classifier head beside the encoder -- goes through ``run_speech --checkpoint``; the HIP path sees
+    merged weights (weights.merge_lora), the oracle applies the adapters UN-MERGED (x W^T + 2 (x A^T) B^T) like the
+    wrapped module does.  Adapters are large on purpose (the merge changes the states by far more than the tolerance)."""
+    from safetensors.torch import save_file
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.TINY_WAVLM if family == "wavlm" else C.TINY_HUBERT
+    base = synthetic_state_dict(geo, 41)
+    g = torch.Generator().manual_seed(42)
+    r, alpha, D = 8, 16.0, geo.hidden
+    ckpt, ref_sd = {}, dict(base)
+    ref_sd["lora_scale"] = torch.tensor(alpha / r)
+    for k, v in base.items():
+        mod, _, leaf = k.rpartition(".")
+        if mod.endswith((".q_proj", ".v_proj")):
+            ckpt[f"wavlm.base_model.model.{mod}.base_layer.{leaf}"] = v
+            if leaf == "weight":
+                A = torch.randn(r, D, generator=g) * 0.3
+                B = torch.randn(D, r, generator=g) * 0.3
+                ckpt[f"wavlm.base_model.model.{mod}.lora_A.default.weight"] = A
+                ckpt[f"wavlm.base_model.model.{mod}.lora_B.default.weight"] = B
+                ref_sd[mod + ".lora_A.weight"], ref_sd[mod + ".lora_B.weight"] = A, B
+        else:
+            ckpt["wavlm.base_model.model." + k] = v
+    ckpt["classifier.0.weight"], ckpt["classifier.0.bias"] = torch.zeros(512, D), torch.zeros(512)     # the fine-tuning head
+    ckpt["classifier.3.weight"], ckpt["classifier.3.bias"] = torch.zeros(8, 512), torch.zeros(8)
+    ck = tmp_path / "lora_ser.safetensors"
+    save_file({k: v.contiguous() for k, v in ckpt.items()}, str(ck))
+    wav_dir, out = tmp_path / "wav", tmp_path / "pt"
+    wav_dir.mkdir()
+    waves = {"a.wav": synth(61, 16000), "b.wav": synth(62, 23457)}
+    for n, w in waves.items():
+        write_wav(wav_dir / n, w)
+    # register the tiny geometry under a name the driver can resolve
+    C._REGISTRY["tiny-lora-test"] = geo
+    try:
+        rc = driver.run_speech(["--ssl_type", "tiny-lora-test", "--wav_dir", str(wav_dir), "--save_path", str(out),
+                                "--checkpoint", str(ck), "--mode", "fp32x", "--n_layer", "-1", "--lora_alpha", "16"])
+    finally:
+        C._REGISTRY.pop("tiny-lora-test")
+    assert rc == 0, capsys.readouterr().out
+    from interspeech_ser_amd.frontend import load_wav_16k
+    worst = changed = 0.0
+    for n in waves:
+        x = load_wav_16k(str(wav_dir / n))
+        with torch.no_grad():
+            ref = O.speech_hidden_states(geo, ref_sd, torch.from_numpy(O.zero_mean_unit_var(x)))[-1]
+            plain = O.speech_hidden_states(geo, base, torch.from_numpy(O.zero_mean_unit_var(x)))[-1]
+        got = torch.load(out / n.replace(".wav", ".pt"))
+        assert got.shape == ref.shape
+        worst = max(worst, float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))))
+        changed = max(changed, float((plain - ref).abs().max()))
+    assert changed > 0.1, changed            # the adapters matter ...
+    assert worst < 1e-3, worst               # ... and the merged HIP path equals the un-merged reference arithmetic
