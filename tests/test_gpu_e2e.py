@@ -430,4 +430,4 @@ def test_encoder_from_device_resident_weights(family):
         hs = enc.forward(enc.upload(waves), lens)
         torch.cuda.synchronize()
         outs.append(hs.states.clone())
-    assert rel_err(outs[1], outs[0]) < 1e-6
+    assert rel_err(outs[1], outs[0]) < 2e-5       # fp64 folds run on the device instead of the host: last-bit differences only
