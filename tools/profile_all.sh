@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round profile set, run on the GPU box from the repo root:   bash tools/profile_all.sh r02
+# Kernel-trace stats of the TIMED path (hipGraph replay of two concurrent utterance groups; the two warm-up forwards
+# before capture are < 2 % of the launches) for every speech config, then the PMC passes on the headline config
+# (separate passes for FETCH_SIZE / WRITE_SIZE / SQ counters, --kernel-trace only, as the MI355X guide prescribes).
+# Raw output under gpurun_out/prof/, summaries under profiles/<tag>_*.
+set -o pipefail
+TAG=${1:-r02}
+OUT=gpurun_out/prof
+mkdir -p $OUT profiles
+cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
+FLAGS="--no-trace --no-cpu-baseline --no-parity --no-e2e"
+stats() {  # name, bench args...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py $FLAGS "$@" > $OUT/$name.json 2> $OUT/$name.err || return 1
+    local f=$(ls $OUT/$name/*/*kernel_stats.csv | head -1)
+    cp "$f" profiles/${TAG}_kernel_stats_$name.csv
+    cp $OUT/$name.json profiles/${TAG}_bench_under_rocprof_$name.json
+    echo "== $name: $(python3 -c "import json;d=json.load(open('$OUT/$name.json'));print(d['value'], d['unit'], d['config']['ms_per_batch'], 'ms/batch', d.get('verified'))")"
+    head -8 "$f" | cut -c1-150
+}
+stats wavlm_large_bf16 --steps 10 || exit 1
+stats wavlm_large_f16 --steps 10 --mode f16 || exit 1
+stats hubert_xlarge_bf16 --steps 5 --ssl_type facebook/hubert-xlarge-ll60k || exit 1
+stats xlsr_2b_bf16 --steps 5 --ssl_type facebook/wav2vec2-xls-r-2b --batch 8 || exit 1
+stats whisper_large_v3_bf16 --steps 3 --reps 4 --ssl_type openai/whisper-large-v3 --seconds 30 || exit 1
+# PMC passes: eager launches (counters are per dispatch), headline workload
+PMC="--steps 2 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
+python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|groups=2"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+    --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_sq.err || exit 1
+python3 tools/pmc_sq_summary.py $OUT/pmc_sq profiles/$TAG
+# Whisper front end alone against HBM bytes (FETCH/WRITE of the logmel kernels come out of the per-kernel CSV)
+WPMC="--steps 1 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS --ssl_type openai/whisper-large-v3 --seconds 30"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_fetch -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_write -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_write.err || exit 1
+python3 tools/pmc_summary.py $OUT/wpmc_fetch $OUT/wpmc_write profiles/${TAG}_whisper "openai/whisper-large-v3|bf16|batch=16x30s|groups=2"
+echo done
