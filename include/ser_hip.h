@@ -202,7 +202,10 @@ int ser_embed_ln(const int32_t* ids, const float* word_emb, const float* pos_emb
 /* K13 Whisper log-mel front end (HF feature_extraction_whisper.py:135-169): packed fp32
  * samples -> [B, n_mels, 3000] fp32 (zero-pad/truncate to 480000, reflect pad, Hann,
  * 400-pt DFT power, mel, log10, per-utterance max-8 floor, (x+4)/4).
- * mel: [201, n_mels] fp32.  work: ser_workspace_bytes(SER_WS_LOGMEL, B, ...) bytes. */
+ * mel: [201, n_mels] fp32.  work: ser_workspace_bytes(SER_WS_LOGMEL, B, ...) bytes, prepared ONCE per buffer by
+ * ser_logmel_init (the DFT twiddle table lives there; the per-utterance maxima are per-block partials reduced by the
+ * finishing pass: no atomics, nothing to reset between calls). */
+int ser_logmel_init(void* work, int B, void* stream);
 int ser_logmel_whisper(const float* wav, const int64_t* sample_offs, int B, const float* mel, int n_mels,
                        float* out, void* work, void* stream);
 
@@ -273,6 +276,14 @@ typedef struct ser_row_center_args {
     float* stats; float* shift; int32_t stat_groups, mode, rows, D;
 } ser_row_center_args;
 
+typedef struct ser_logmel_args {
+    const float* wav; const int64_t* sample_offs; const float* mel; float* out; void* work; int32_t B, n_mels;
+} ser_logmel_args;
+
+typedef struct ser_pack_act_args {
+    const float* x; void* out; int64_t ldo; int64_t out_plane_stride; int32_t B, C, T, halo, mode, reserved0;
+} ser_pack_act_args;
+
 typedef struct ser_wave_frames_args {
     const float* wav; const int64_t* sample_offs; const int32_t* frame_offs; int32_t B, k, stride, mode;
     void* out; int64_t out_plane_stride; void* work; int32_t total_rows, reserved0;
@@ -283,6 +294,8 @@ typedef struct ser_wave_frames_args {
 #define SER_OP_LAYERNORM 3
 #define SER_OP_WAVE_FRAMES 4
 #define SER_OP_ROW_CENTER 5
+#define SER_OP_LOGMEL 6
+#define SER_OP_PACK_ACT 7
 typedef struct ser_cmd {
     int32_t op, reserved0;
     union {
@@ -291,6 +304,8 @@ typedef struct ser_cmd {
         ser_layernorm_args   layernorm;
         ser_wave_frames_args wave_frames;
         ser_row_center_args  row_center;
+        ser_logmel_args      logmel;
+        ser_pack_act_args    pack_act;
     } u;
 } ser_cmd;
 

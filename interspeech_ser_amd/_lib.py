@@ -91,9 +91,21 @@ class RowCenterArgs(C.Structure):
     ]
 
 
+class LogmelArgs(C.Structure):
+    """Mirror of ``ser_logmel_args``."""
+    _fields_ = [("wav", c_void_p), ("sample_offs", c_void_p), ("mel", c_void_p), ("out", c_void_p), ("work", c_void_p),
+                ("B", C.c_int32), ("n_mels", C.c_int32)]
+
+
+class PackActArgs(C.Structure):
+    """Mirror of ``ser_pack_act_args``."""
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("ldo", c_i64), ("out_plane_stride", c_i64),
+                ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("halo", C.c_int32), ("mode", C.c_int32), ("reserved0", C.c_int32)]
+
+
 class _CmdUnion(C.Union):
     _fields_ = [("gemm", GemmArgs), ("attention", AttentionArgs), ("layernorm", LayerNormArgs), ("wave_frames", WaveFramesArgs),
-                ("row_center", RowCenterArgs)]
+                ("row_center", RowCenterArgs), ("logmel", LogmelArgs), ("pack_act", PackActArgs)]
 
 
 class Cmd(C.Structure):
@@ -101,9 +113,10 @@ class Cmd(C.Structure):
     _fields_ = [("op", C.c_int32), ("reserved0", C.c_int32), ("u", _CmdUnion)]
 
 
-OP_GEMM, OP_ATTENTION, OP_LAYERNORM, OP_WAVE_FRAMES, OP_ROW_CENTER = 1, 2, 3, 4, 5
+OP_GEMM, OP_ATTENTION, OP_LAYERNORM, OP_WAVE_FRAMES, OP_ROW_CENTER, OP_LOGMEL, OP_PACK_ACT = 1, 2, 3, 4, 5, 6, 7
 STRUCT_MIRRORS = {"ser_gemm_args": GemmArgs, "ser_attention_args": AttentionArgs, "ser_layernorm_args": LayerNormArgs,
-                  "ser_wave_frames_args": WaveFramesArgs, "ser_row_center_args": RowCenterArgs, "ser_cmd": Cmd}
+                  "ser_wave_frames_args": WaveFramesArgs, "ser_row_center_args": RowCenterArgs, "ser_logmel_args": LogmelArgs,
+                  "ser_pack_act_args": PackActArgs, "ser_cmd": Cmd}
 
 _SIGNATURES = {
     "ser_version": (c_int, []),
@@ -124,6 +137,7 @@ _SIGNATURES = {
                               c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ser_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                              c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ser_logmel_init": (c_int, [c_void_p, c_int, c_void_p]),
     "ser_logmel_whisper": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ser_pack_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "ser_mean4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),

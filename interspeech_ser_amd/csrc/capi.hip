@@ -29,8 +29,8 @@ extern "C" size_t ser_workspace_bytes(int op, int B, int T, int D, int H, int mo
     (void)T; (void)D; (void)H; (void)mode;
     switch (op) {
         case SER_WS_LOGMEL:
-            // one 256-byte granule per utterance (running max) + the fp64 twiddle table [400][201]x2
-            return (size_t)(B > 0 ? B : 1) * 256 + (size_t)400 * 201 * 16;
+            // per-block partial maxima [B][256] floats + the fp64 twiddle table [400][201]x2 (ser_logmel_init)
+            return (size_t)(B > 0 ? B : 1) * 1024 + (size_t)400 * 201 * 16;
         case SER_WS_WAVE_FRAMES:
             return (size_t)(B > 0 ? B : 1) * 64 * 2 * sizeof(double);      // [B][64] partial (sum, sum^2)
         default:
@@ -72,6 +72,16 @@ extern "C" int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void*
                 const ser_row_center_args& a = c.u.row_center;
                 rc = ser_row_center(a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride, a.stats, a.stat_groups, a.shift,
                                     a.mode, a.rows, a.D, stream);
+                break;
+            }
+            case SER_OP_LOGMEL: {
+                const ser_logmel_args& a = c.u.logmel;
+                rc = ser_logmel_whisper(a.wav, a.sample_offs, a.B, a.mel, a.n_mels, a.out, a.work, stream);
+                break;
+            }
+            case SER_OP_PACK_ACT: {
+                const ser_pack_act_args& a = c.u.pack_act;
+                rc = ser_pack_act(a.x, a.B, a.C, a.T, a.halo, a.out, a.ldo, a.out_plane_stride, a.mode, stream);
                 break;
             }
             default:

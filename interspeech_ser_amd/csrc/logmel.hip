@@ -19,18 +19,14 @@
 #define LM_SAMPLES 480000
 #define LM_FR 16              // frames per block
 
-__device__ __forceinline__ int f2ord(float f) {
-    const int i = __float_as_int(f);
-    return i >= 0 ? i : i ^ 0x7fffffff;
-}
-__device__ __forceinline__ float ord2f(int i) {
-    return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
-}
+#define LM_NBLK ((LM_FRAMES + LM_FR - 1) / LM_FR)    // frame blocks per utterance (188)
+#define LM_BMAX 256                                   // partial-maximum slots per utterance (>= LM_NBLK)
 
-// work layout: [0, B*64) ints (one 256-byte granule per utterance max), then the twiddle table
-__global__ void logmel_init_kernel(int* umax, int B, double2* tw) {
+// work layout: the fp64 twiddle table [400][201] (built once per buffer by ser_logmel_init), then [B][LM_BMAX] floats
+// (per-block maxima of one call)
+#define LM_TW_BYTES ((size_t)LM_NFFT * LM_BINS * sizeof(double2))
+__global__ void logmel_init_kernel(double2* tw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) umax[i * 64] = f2ord(-INFINITY);
     if (i < LM_NFFT * LM_BINS) {
         const int n = i / LM_BINS, k = i - n * LM_BINS;
         const int r = (n * k) % LM_NFFT;                     // exact argument reduction
@@ -43,7 +39,7 @@ __global__ void logmel_init_kernel(int* umax, int B, double2* tw) {
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, const int64_t* __restrict__ offs,
                                                      const float* __restrict__ mel, int n_mels,
                                                      const double2* __restrict__ tw, float* __restrict__ out,
-                                                     int* __restrict__ umax) {
+                                                     float* __restrict__ bmax) {
     __shared__ float xw[LM_FR][LM_NFFT];
     __shared__ float pw[LM_FR][LM_BINS + 3];
     const int b = blockIdx.y, f0 = blockIdx.x * LM_FR, tid = threadIdx.x;
@@ -100,18 +96,38 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
             }
         }
     }
+    // block maximum -> its own slot: the finishing pass reduces the 188 slots of an utterance (no atomics, no reset)
+    __shared__ float wmax[4];
     lmax = wave_max(lmax);
-    if ((tid & 63) == 0) atomicMax(&umax[b * 64], f2ord(lmax));
+    if ((tid & 63) == 0) wmax[tid >> 6] = lmax;
+    __syncthreads();
+    if (tid == 0) bmax[b * LM_BMAX + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
-__global__ void logmel_finish_kernel(float* __restrict__ out, const int* __restrict__ umax, int n_mels) {
+__global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ out, const float* __restrict__ bmax, int n_mels) {
     const int b = blockIdx.y;
-    const int64_t per = (int64_t)n_mels * LM_FRAMES;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[4];
+    float m = threadIdx.x < LM_NBLK ? bmax[b * LM_BMAX + threadIdx.x] : -INFINITY;
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int64_t per = (int64_t)n_mels * LM_FRAMES;                 // a multiple of 4 (3000 frames)
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= per) return;
-    const float mx = ord2f(umax[b * 64]);
-    float* o = out + (int64_t)b * per;
-    o[i] = (fmaxf(o[i], mx - 8.0f) + 4.0f) / 4.0f;
+    f32x4* o = (f32x4*)(out + (int64_t)b * per + i);
+    f32x4 v = *o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (fmaxf(v[j], mx - 8.0f) + 4.0f) / 4.0f;
+    *o = v;
+}
+
+extern "C" int ser_logmel_init(void* work, int B, void* stream) {
+    (void)B;
+    if (!work) return ser_fail(-1, "ser_logmel_init: bad arguments");
+    double2* tw = (double2*)work;
+    hipLaunchKernelGGL(logmel_init_kernel, dim3((LM_NFFT * LM_BINS + 255) / 256), dim3(256), 0, (hipStream_t)stream, tw);
+    return ser_check_launch("ser_logmel_init");
 }
 
 extern "C" int ser_logmel_whisper(const float* wav, const int64_t* sample_offs, int B, const float* mel, int n_mels,
@@ -119,13 +135,10 @@ extern "C" int ser_logmel_whisper(const float* wav, const int64_t* sample_offs, 
     if (!wav || !sample_offs || !mel || !out || !work || B <= 0 || n_mels <= 0)
         return ser_fail(-1, "ser_logmel_whisper: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    int* umax = (int*)work;
-    double2* tw = (double2*)((char*)work + (((size_t)B * 256 + 255) / 256) * 256);
-    const int ninit = LM_NFFT * LM_BINS > B ? LM_NFFT * LM_BINS : B;
-    hipLaunchKernelGGL(logmel_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, s, umax, B, tw);
-    hipLaunchKernelGGL(logmel_kernel, dim3((LM_FRAMES + LM_FR - 1) / LM_FR, B), dim3(256), 0, s, wav, sample_offs, mel,
-                       n_mels, tw, out, umax);
+    const double2* tw = (const double2*)work;                                            // ser_logmel_init
+    float* bmax = (float*)((char*)work + LM_TW_BYTES);
+    hipLaunchKernelGGL(logmel_kernel, dim3(LM_NBLK, B), dim3(256), 0, s, wav, sample_offs, mel, n_mels, tw, out, bmax);
     const int64_t per = (int64_t)n_mels * LM_FRAMES;
-    hipLaunchKernelGGL(logmel_finish_kernel, dim3((unsigned)((per + 255) / 256), B), dim3(256), 0, s, out, umax, n_mels);
+    hipLaunchKernelGGL(logmel_finish_kernel, dim3((unsigned)((per / 4 + 255) / 256), B), dim3(256), 0, s, out, bmax, n_mels);
     return ser_check_launch("ser_logmel_whisper");
 }

@@ -158,8 +158,6 @@ class _Extractor:
         """Enqueue upload -> forward -> selection -> D2H of one ragged batch on slot ``slot``'s stream; returns a
         ticket for ``collect``.  Nothing here waits for the GPU."""
         from .engine import mean_last4
-        if self.whisper:
-            raise RuntimeError("the pipelined path serves the wav2vec2-style encoders")
         st = self.__dict__.setdefault("_streams", {})
         if slot not in st:
             st[slot] = torch.cuda.Stream(device=self.enc.device)
@@ -188,7 +186,10 @@ class _Extractor:
         the slot's next ``submit``; ``hold`` defers that until the given futures are done)."""
         ticket["event"].synchronize()
         host, fo = ticket["host"], ticket["frame_offs"]
-        return [host[fo[b]: fo[b + 1]] for b in range(len(ticket["lengths"]))]
+        rows = [host[fo[b]: fo[b + 1]] for b in range(len(ticket["lengths"]))]
+        if self.whisper:                                      # a20: min(ceil(len / 320), D) rows (preprocess_whisper.py:49-50,75-76)
+            rows = [r[: whisper_saved_rows(n, r.shape[1])] for r, n in zip(rows, ticket["lengths"])]
+        return rows
 
     def hold(self, slot: int, futures) -> None:
         self.__dict__.setdefault("_held", {})[slot] = list(futures)
@@ -292,7 +293,7 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
     audio_s = 0.0
     bar = tqdm(total=len(mine), desc="Extracting features", disable=(rank != 0))
     from collections import deque
-    pipelined = getattr(ex, "pipelined", not whisper)
+    pipelined = getattr(ex, "pipelined", True)           # both encoder families run through the two-slot pipeline
     with ThreadPoolExecutor(max_workers=max(1, args.num_workers)) as pool:
         pending = pool.map(decode, batches[0]) if batches else []
         writes = []

@@ -850,6 +850,7 @@ class WhisperEncoder(_EncoderBase):
         pl["mel"] = torch.empty((B, nm, T1), dtype=torch.float32, device=dev)
         ws = lib.ser_workspace_bytes(_lib.WS_LOGMEL, B, 0, 0, 0, self.stem_mode)
         pl["work"] = torch.empty(ws, dtype=torch.uint8, device=dev)
+        check(lib.ser_logmel_init(pl["work"].data_ptr(), B, _stream()), "ser_logmel_init")     # DFT twiddles: once per buffer
         pl["mel_act"] = self._new_act(B * Tp, nm, stem=True)
         pl["c1_act"] = self._new_act(B * Tp, D, zero=True, stem=True)
         b_idx = np.repeat(np.arange(B, dtype=np.int64), T1)
@@ -864,7 +865,7 @@ class WhisperEncoder(_EncoderBase):
         pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
         pl["first_groups"] = 2
         self._layer_buffers(pl, M, pl["first_groups"])
-        if len(self._cache) >= 3:
+        if len(self._cache) >= 6:                       # two pipeline slots x (full batch, tail batch) + slack
             self._cache.pop(next(iter(self._cache)))
         self._cache[key_full] = pl
         return pl
@@ -872,30 +873,76 @@ class WhisperEncoder(_EncoderBase):
     upload = SpeechEncoder.upload
     download = SpeechEncoder.download
 
+    def _logmel(self, pl, packed_wave: torch.Tensor) -> None:
+        rec = self._rec
+        if rec is not None:
+            a = rec.slot("logmel")
+            a.wav, a.sample_offs, a.mel = packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), self.mel.data_ptr()
+            a.out, a.work, a.B, a.n_mels = pl["mel"].data_ptr(), pl["work"].data_ptr(), pl["B"], self.geo.n_mels
+            rec.inputs["wav"] = a
+            rec.commit(_lib.OP_LOGMEL, a)
+            return
+        check(lib.ser_logmel_whisper(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["B"], self.mel.data_ptr(),
+                                     self.geo.n_mels, pl["mel"].data_ptr(), pl["work"].data_ptr(), self._s()),
+              "ser_logmel_whisper")
+
+    @_on_stream
     def log_mel(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> torch.Tensor:
         """a16: [B, n_mels, 3000] fp32 input_features, computed on the GPU."""
         pl = self._plan(lengths, slot)
-        check(lib.ser_logmel_whisper(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["B"], self.mel.data_ptr(),
-                                     self.geo.n_mels, pl["mel"].data_ptr(), pl["work"].data_ptr(), _stream()),
-              "ser_logmel_whisper")
+        self._logmel(pl, packed_wave)
         return pl["mel"]
 
+    use_tape = True          # replay a recorded command list (one foreign call per forward), like SpeechEncoder
+
+    @_on_stream
     def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
-        return self.forward_features(self.log_mel(packed_wave, lengths, slot), lengths, slot)
+        """packed raw samples -> log-mel (a16) -> encoder (a17): the reference's processor + model.encoder calls
+        (preprocess_whisper.py:48,57).  Every buffer is a function of (slot, B), so the ~170 launches are recorded once
+        per plan and replayed with one ser_run call; only the waveform pointer changes from batch to batch."""
+        pl = self._plan(lengths, slot)
+        if not self.use_tape or self.gemm_trace is not None or self.block_trace is not None:
+            self._logmel(pl, packed_wave)
+            self._encoder_launches(pl, pl["mel"])
+        else:
+            tape = pl.get("tape")
+            if tape is None:
+                self._rec = tape = Tape()
+                try:
+                    self._logmel(pl, packed_wave)
+                    self._encoder_launches(pl, pl["mel"])
+                finally:
+                    self._rec = None
+                pl["tape"] = tape
+            tape.inputs["wav"].wav = packed_wave.data_ptr()
+            tape.run({}, self._s())
+        return HiddenStates(pl["states"], pl["frame_offs_host"])
 
     @_on_stream
     def forward_features(self, input_features: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
-        """a17: ``model.encoder(input_features, output_hidden_states=True).hidden_states``."""
+        """a17: ``model.encoder(input_features, output_hidden_states=True).hidden_states`` on caller-supplied features."""
         geo = self.geo
         pl = self._plan(lengths, slot)
+        if tuple(input_features.shape) != (pl["B"], geo.n_mels, self.N_FRAMES):
+            raise ValueError(f"Whisper expects input_features of shape {(pl['B'], geo.n_mels, self.N_FRAMES)}, "
+                             f"got {tuple(input_features.shape)}")
+        self._encoder_launches(pl, input_features)
+        return HiddenStates(pl["states"], pl["frame_offs_host"])
+
+    def _encoder_launches(self, pl, input_features: torch.Tensor) -> None:
+        geo = self.geo
         B, M, D, nm = pl["B"], pl["M"], geo.hidden, geo.n_mels
         T1, T2 = self.N_FRAMES, geo.max_source_positions
-        if tuple(input_features.shape) != (B, nm, T1):
-            raise ValueError(f"Whisper expects input_features of shape {(B, nm, T1)}, got {tuple(input_features.shape)}")
-        st = _stream()
         ma = pl["mel_act"]
-        check(lib.ser_pack_act(input_features.data_ptr(), B, nm, T1, 1, ma.ptr, nm, ma.plane_stride, self.stem_mode, st),
-              "ser_pack_act")
+        rec = self._rec
+        if rec is not None:
+            a = rec.slot("pack_act")
+            a.x, a.out, a.ldo, a.out_plane_stride = input_features.data_ptr(), ma.ptr, nm, ma.plane_stride
+            a.B, a.C, a.T, a.halo, a.mode = B, nm, T1, 1, self.stem_mode
+            rec.commit(_lib.OP_PACK_ACT, a)
+        else:
+            check(lib.ser_pack_act(input_features.data_ptr(), B, nm, T1, 1, ma.ptr, nm, ma.plane_stride, self.stem_mode,
+                                   self._s()), "ser_pack_act")
         # stem: gelu(conv1 k3 p1), gelu(conv2 k3 s2 p1) + embed_positions -> hidden_states[0]
         self._gemm(ma, self.conv1, B * T1, a_rowoff=pl["c1_rowoff"], act=_lib.ACT_GELU, out_act=pl["c1_act"],
                    out_rowmap=pl["c1_rowmap"], stem=True)
@@ -903,7 +950,6 @@ class WhisperEncoder(_EncoderBase):
         self._gemm(pl["c1_act"], self.conv2, M, a_rowoff=pl["c2_rowoff"], act=_lib.ACT_GELU, residual=self.pos_emb,
                    ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D, stem=True)
         self._run_layers(pl, states, pl["first_groups"], B, T2)
-        return HiddenStates(states, pl["frame_offs_host"])
 
 
 class TextEncoder(_EncoderBase):

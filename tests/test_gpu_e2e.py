@@ -431,3 +431,46 @@ def test_encoder_from_device_resident_weights(family):
         torch.cuda.synchronize()
         outs.append(hs.states.clone())
     assert rel_err(outs[1], outs[0]) < 2e-5       # fp64 folds run on the device instead of the host: last-bit differences only
+
+
+def test_whisper_command_list_and_pipeline_equal_eager():
+    """Whisper is first-class on the host side too: the recorded command list (log-mel -> stem -> layers in one ser_run)
+    is bit-identical to launching kernel by kernel, and the two-slot pipeline (streams, pinned D2H, the reference's
+    crop applied on collect) is bit-identical to the synchronous path -- across batches of different sizes and lengths."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.driver import _Extractor
+    from interspeech_ser_amd.engine import WhisperEncoder
+    from interspeech_ser_amd.frontend import whisper_saved_rows
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_WHISPER
+    sd = synthetic_state_dict(geo, 6)
+    taped = WhisperEncoder(geo, sd, "cuda:0", mode="bf16")
+    eager = WhisperEncoder(geo, sd, "cuda:0", mode="bf16")
+    eager.use_tape = False
+    rng = np.random.default_rng(3)
+    batches = []
+    for k in range(5):
+        lens = [int(n) for n in rng.integers(2000, 200000, size=int(rng.integers(1, 4)))]
+        batches.append([synth_wave(40 * k + i, n) for i, n in enumerate(lens)])
+    batches.append(batches[1])
+    for waves in batches:
+        lens = [len(w) for w in waves]
+        a = taped.forward(taped.upload(waves), lens)
+        b = eager.forward(eager.upload(waves), lens)
+        torch.cuda.synchronize()
+        assert torch.equal(a.states, b.states)
+    assert any("tape" in pl for pl in taped._cache.values()) and not any("tape" in pl for pl in eager._cache.values())
+    ex = _Extractor.__new__(_Extractor)
+    ex.whisper, ex.average, ex.geo, ex.enc = True, False, geo, taped
+    want = [[t.clone() for t in ex.extract(b, 2)] for b in batches]
+    torch.cuda.synchronize()
+    got, inflight = [], []
+    for k, b in enumerate(batches):
+        inflight.append(ex.submit(b, 2, slot=k % 2))
+        if len(inflight) > 1:
+            got.append([t.clone() for t in ex.collect(inflight.pop(0))])
+    got.append([t.clone() for t in ex.collect(inflight.pop(0))])
+    for g, w, waves in zip(got, want, batches):
+        assert len(g) == len(w)
+        for x, y, wv in zip(g, w, waves):
+            assert x.shape == y.shape == (whisper_saved_rows(len(wv), geo.hidden), geo.hidden) and torch.equal(x, y)

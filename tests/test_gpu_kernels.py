@@ -741,6 +741,7 @@ def test_logmel_whisper(L, golden_dir):
     out = torch.empty(B, 128, 3000, device=DEV)
     ws = L.lib.ser_workspace_bytes(L.WS_LOGMEL, B, 0, 0, 0, 1)
     work = torch.empty(ws, dtype=torch.uint8, device=DEV)
+    L.check(L.lib.ser_logmel_init(work.data_ptr(), B, stream()), "ser_logmel_init")          # twiddle table: once per work buffer
     L.check(L.lib.ser_logmel_whisper(packed.data_ptr(), offs.data_ptr(), B, mel.data_ptr(), 128, out.data_ptr(),
                                      work.data_ptr(), stream()))
     got = out.cpu().numpy()
