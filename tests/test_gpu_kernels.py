@@ -25,8 +25,8 @@ def stream():
 
 
 def mode_tol(mode, bf16, fp32x):
-    """bound per numerics mode: fp16 operands (mode 3) round 8x finer than bf16; gate at 1/3 of the bf16 bound."""
-    return {1: bf16, 2: fp32x, 3: max(bf16 / 3, fp32x)}[mode]
+    """bound per numerics mode: fp16 operands (mode 3) round 8x finer than bf16; gate at 1/2.5 of the bf16 bound."""
+    return {1: bf16, 2: fp32x, 3: max(bf16 / 2.5, fp32x)}[mode]
 
 
 def act_dtype(mode):
