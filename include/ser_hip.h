@@ -114,7 +114,7 @@ typedef struct ser_gemm_args {
     const float*   ln_gamma;       /* [N] or NULL */
     const float*   ln_beta;        /* [N] */
     float          ln_eps;
-    int32_t        tile_cfg;       /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile */
+    int32_t        tile_cfg;       /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile, 4 = 256x256 on 4 waves of 128x128 */
     /* DEFERRED LayerNorm of the A operand (encoder layers: LN -> Linear, HF modeling_wavlm.py:357-358,
      * 366): the LayerNorm kernel and its HBM round trip disappear.  With W' = W * gamma (folded at load),
      *   LN(x) W^T + b = rstd_m * (x W'^T - mu_m * colsum(W')_n) + (beta W^T + b)_n
@@ -143,7 +143,8 @@ typedef struct ser_gemm_args {
     const float*   shift_in;       /* [M] absolute row mean of the residual rows, or NULL (0) */
     float*         shift_out;      /* [M] or NULL (no shifting) */
     float          shift_const;
-    int32_t        reserved1;
+    int32_t        out_mode;       /* format of out_act: 0 = mode; SER_MODE_FP16 with mode == SER_MODE_FP32X converts (one plane of
+                                    * fp16 written from a 3-product GEMM: the stem -> layers boundary of the host's "f16" mode) */
     const float*   ln_shift;       /* [M] shift of the A rows / their partials (consumer), or NULL */
     float*         mean_out;       /* [M] absolute row mean of the A rows (consumer), or NULL */
 } ser_gemm_args;

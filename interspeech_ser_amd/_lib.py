@@ -44,7 +44,7 @@ class GemmArgs(C.Structure):
         ("ln_stats_in", c_void_p), ("ln_groups", C.c_int32), ("ln_colsum", c_void_p),
         ("stat_out", c_void_p), ("stat_groups", C.c_int32), ("f32_col_begin", C.c_int32),
         ("col_scale", c_float), ("col_scale_end", C.c_int32),
-        ("shift_in", c_void_p), ("shift_out", c_void_p), ("shift_const", c_float), ("reserved1", C.c_int32),
+        ("shift_in", c_void_p), ("shift_out", c_void_p), ("shift_const", c_float), ("out_mode", C.c_int32),
         ("ln_shift", c_void_p), ("mean_out", c_void_p),
     ]
 

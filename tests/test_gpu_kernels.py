@@ -94,6 +94,10 @@ def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
         si = kw.get("shift_in")
         g.shift_in = si.data_ptr() if si is not None else None
         g.shift_out, g.shift_const = kw["shift_out"].data_ptr(), kw.get("shift_const", 0.0)
+    if kw.get("out_mode"):
+        g.out_mode = kw["out_mode"]
+        out_act = torch.zeros((1, kw.get("out_act_rows", M), ncols), dtype=act_dtype(kw["out_mode"]), device=DEV)
+        g.out_act, g.ldo_act, g.out_plane_stride = out_act.data_ptr(), ncols, out_act.shape[1] * ncols
     if kw.get("mean_out") is not None:
         ls = kw.get("ln_shift")
         g.ln_shift = ls.data_ptr() if ls is not None else None
@@ -241,6 +245,23 @@ def test_shifted_operand_chain_large_row_mean(L, mode, cfg):
     err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < mode_tol(mode, 3e-2, 1e-4), err
     assert (m1.cpu().double() - x1.mean(1)).abs().max() < 1e-3                  # the consumer reports the absolute row mean
+
+
+def test_gemm_fp32x_in_fp16_out(L):
+    """The stem -> layers boundary of the "f16" numerics mode: a 3-product FP32X GEMM whose operand copy is written as one
+    fp16 plane (ser_gemm_args.out_mode); the copy is the fp16 rounding of the fp32 result, and other conversions are refused."""
+    M, N, K = 300, 200, 192
+    g = torch.Generator().manual_seed(8)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    out, oact = run_gemm(L, to_act(A, 2), to_act(W, 2), M, N, K, 2, out_mode=3)
+    ref = A.double() @ W.double().T
+    assert (out.cpu().double() - ref).abs().max() < 2e-4
+    assert oact.dtype == torch.float16 and torch.equal(oact[0].cpu(), out.cpu().to(torch.float16))
+    ga = L.GemmArgs()
+    a1, w1 = to_act(A, 1), to_act(W, 1)
+    ga.A, ga.W, ga.M, ga.N, ga.K, ga.groups, ga.mode, ga.out_mode, ga.lda = a1.data_ptr(), w1.data_ptr(), M, N, K, 1, 1, 3, K
+    ga.out_f32, ga.ldo_f32 = out.data_ptr(), N
+    assert L.lib.ser_gemm(C.byref(ga), stream()) < 0 and b"out_mode" in L.lib.ser_last_error()
 
 
 @pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 2e-5)])
