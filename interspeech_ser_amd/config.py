@@ -19,7 +19,7 @@ FAMILY_WAV2VEC2 = "wav2vec2"
 FAMILY_HUBERT = "hubert"
 FAMILY_WHISPER = "whisper"
 FAMILY_ROBERTA = "roberta"      # text side of the bimodal heads (next row 8f-1)
-FAMILY_DEBERTA = "deberta"      # DeBERTa-v2/v3 variant of the text side: ORACLE + fixtures only so far (no HIP path yet)
+FAMILY_DEBERTA = "deberta"      # DeBERTa-v2/v3 variant of the text side (engine.DebertaEncoder, csrc/deberta.hip)
 
 SPEECH_FAMILIES = (FAMILY_WAVLM, FAMILY_WAV2VEC2, FAMILY_HUBERT)
 
