@@ -29,8 +29,8 @@ extern "C" size_t ser_workspace_bytes(int op, int B, int T, int D, int H, int mo
     (void)T; (void)D; (void)H; (void)mode;
     switch (op) {
         case SER_WS_LOGMEL:
-            // per-block partial maxima [B][256] floats + the fp64 twiddle table [400][208] x (cos, -sin) (ser_logmel_init)
-            return (size_t)(B > 0 ? B : 1) * 1024 + (size_t)400 * 208 * 16;
+            // per-block partial maxima [B][256] floats + the fp64 twiddle table [400][208] x (cos, -sin) + the Hann window (ser_logmel_init)
+            return (size_t)(B > 0 ? B : 1) * 1024 + (size_t)400 * 208 * 16 + 400 * 4;
         case SER_WS_WAVE_FRAMES:
             return (size_t)(B > 0 ? B : 1) * 64 * 2 * sizeof(double);      // [B][64] partial (sum, sum^2)
         default:

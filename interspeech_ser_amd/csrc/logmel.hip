@@ -28,11 +28,13 @@
 // work layout: the fp64 twiddle table [400][208] of (cos, -sin) (built once per buffer by ser_logmel_init), then
 // [B][LM_BMAX] floats (per-block maxima of one call)
 #define LM_TW_BYTES ((size_t)LM_NFFT * LM_BB * 16 * sizeof(double2))
+#define LM_HANN_BYTES ((size_t)LM_NFFT * sizeof(float))     // periodic Hann window, after the twiddles
 
 typedef __attribute__((ext_vector_type(4))) double f64x4;
 
 __global__ void logmel_init_kernel(double2* tw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < LM_NFFT) ((float*)((char*)tw + LM_TW_BYTES))[i] = 0.5f - 0.5f * cospif(2.0f * (float)i / (float)LM_NFFT);
     if (i < LM_NFFT * LM_BB * 16) {
         const int n = i / (LM_BB * 16), k = i - n * (LM_BB * 16);
         double s = 0.0, c = 0.0;
@@ -50,7 +52,7 @@ __global__ void logmel_init_kernel(double2* tw) {
 // 201 of 256 lanes.  Wave w owns the 16-bin column blocks w, w+4, w+8(, w+12); one 16-byte load of (cos, -sin) feeds
 // the re and the im MFMA of a block.  Operand lane maps (MI355X guide): A[i = lane & 15][k = lane >> 4],
 // B[k = lane >> 4][j = lane & 15], D[row = (lane >> 4) + 4 r][col = lane & 15].
-__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, const int64_t* __restrict__ offs,
+__global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ wav, const int64_t* __restrict__ offs,
                                                      const float* __restrict__ mel, int n_mels,
                                                      const double2* __restrict__ tw, float* __restrict__ out,
                                                      float* __restrict__ bmax) {
@@ -59,14 +61,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t s0 = offs[b];
     const int64_t len = offs[b + 1] - s0;
+    const float* hann = (const float*)((const char*)tw + LM_TW_BYTES);
     for (int i = tid; i < LM_FR * LM_NFFT; i += 256) {
         const int f = i / LM_NFFT, n = i - f * LM_NFFT;
         int s = (f0 + f) * LM_HOP - LM_NFFT / 2 + n;
         if (s < 0) s = -s;
         if (s >= LM_SAMPLES) s = 2 * (LM_SAMPLES - 1) - s;
         const float x = (s < len) ? wav[s0 + s] : 0.f;
-        const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)LM_NFFT);
-        lds[f * LM_XP + n] = x * w;
+        lds[f * LM_XP + n] = x * hann[n];
     }
     __syncthreads();
 
@@ -128,10 +130,15 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         float acc[LM_FR / 2];
 #pragma unroll
         for (int f = 0; f < LM_FR / 2; ++f) acc[f] = 0.f;
-        for (int k = 0; k < LM_BINS; ++k) {
-            const float w = mel[k * n_mels + m];
+        // 8 filter weights requested per pass (201 = 25 x 8 + 1): one L2 latency per 8 bins instead of one per bin
+        for (int k0 = 0; k0 < LM_BINS; k0 += 8) {
+            float w[8];
 #pragma unroll
-            for (int f = 0; f < LM_FR / 2; ++f) acc[f] = fmaf(w, pw[(fb + f) * LM_PP + k], acc[f]);
+            for (int u = 0; u < 8; ++u) w[u] = (k0 + u < LM_BINS) ? mel[(k0 + u) * n_mels + m] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int f = 0; f < LM_FR / 2; ++f) acc[f] = fmaf(w[u], pw[(fb + f) * LM_PP + k0 + u], acc[f]);
         }
         float* orow = out + ((int64_t)b * n_mels + m) * LM_FRAMES + f0 + fb;
 #pragma unroll
@@ -187,7 +194,7 @@ extern "C" int ser_logmel_whisper(const float* wav, const int64_t* sample_offs, 
         return ser_fail(-1, "ser_logmel_whisper: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const double2* tw = (const double2*)work;                                            // ser_logmel_init
-    float* bmax = (float*)((char*)work + LM_TW_BYTES);
+    float* bmax = (float*)((char*)work + LM_TW_BYTES + LM_HANN_BYTES);
     hipLaunchKernelGGL(logmel_kernel, dim3(LM_NBLK, B), dim3(256), 0, s, wav, sample_offs, mel, n_mels, tw, out, bmax);
     const int64_t per = (int64_t)n_mels * LM_FRAMES;
     hipLaunchKernelGGL(logmel_finish_kernel, dim3((unsigned)((per / 4 + 255) / 256), B), dim3(256), 0, s, out, bmax, n_mels);
