@@ -114,7 +114,7 @@ typedef struct ser_gemm_args {
     const float*   ln_gamma;       /* [N] or NULL */
     const float*   ln_beta;        /* [N] */
     float          ln_eps;
-    int32_t        tile_cfg;       /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile, 4 = 256x256 on 4 waves of 128x128 */
+    int32_t        tile_cfg;       /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile */
     /* DEFERRED LayerNorm of the A operand (encoder layers: LN -> Linear, HF modeling_wavlm.py:357-358,
      * 366): the LayerNorm kernel and its HBM round trip disappear.  With W' = W * gamma (folded at load),
      *   LN(x) W^T + b = rstd_m * (x W'^T - mu_m * colsum(W')_n) + (beta W^T + b)_n

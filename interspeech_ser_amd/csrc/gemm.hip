@@ -49,7 +49,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // WM x WN waves, each TM x TN MFMA tiles of 16x16; BK = K tile; ST = ring stages.
 // OM: format of the out_act copy (== MODE unless the launch converts, e.g. an FP32X stem GEMM feeding FP16 layers).
 template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
-__global__ __launch_bounds__(64 * WM * WN, (TM * TN >= 64) ? 1 : 2)      // 128x128 wave tiles: 256 accumulators, one wave per SIMD
+__global__ __launch_bounds__(64 * WM * WN, 2)
 void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -230,7 +230,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             // all k-steps' fragments are requested up front: the LDS reads of step s+1 complete under the
             // MFMAs of step s (the compiler places counted lgkmcnt waits between the clusters)
             // (PIPE; the 128x64-per-wave configuration has no registers to spare and loads per step)
-            constexpr bool PIPE = (TM * TN * 4 + KS * (TM + TN) * 4) <= 208 || TM * TN >= 64;
+            constexpr bool PIPE = (TM * TN * 4 + KS * (TM + TN) * 4) <= 208;
             bf16x8 af[KS][TM], wf[KS][TN];
             if constexpr (PIPE) {
 #pragma unroll
@@ -471,7 +471,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_256x256_W4 = 3, CFG_LN512 = 4, CFG_LN512_M64 = 5, CFG_LN512_M32 = 6, CFG_128x64 = 7 };
+enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN512_M64 = 4, CFG_LN512_M32 = 5, CFG_128x64 = 6 };
 
 template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
 static hipError_t launch_mode(const ser_gemm_args* a, dim3 grid, dim3 block, int LDS, hipStream_t s) {
@@ -543,7 +543,7 @@ static int pick_cfg(const ser_gemm_args* a) {
             return n;
         }();
         for (int i = 0; i < nrules; ++i)
-            if (rules[i].n == a->N && rules[i].k == a->K && rules[i].cfg >= 0 && rules[i].cfg <= CFG_256x256_W4) return rules[i].cfg;
+            if (rules[i].n == a->N && rules[i].k == a->K && rules[i].cfg >= 0 && rules[i].cfg <= CFG_256x256) return rules[i].cfg;
     }
     const long t256x256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
     static const long t256_min = [] {                   // tuning knob (tools/): SER_GEMM_T256_MIN=<tiles>
@@ -593,7 +593,7 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
     if ((a->ldo_act % 8) || (a->c_group_stride % 8)) return ser_fail(-18, "ser_gemm: act pitch / group stride must be multiples of 8");
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
-    if (a->tile_cfg < 0 || a->tile_cfg > 4) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..4)", a->tile_cfg);
+    if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
     hipStream_t s = (hipStream_t)stream;
     if (a->mode == SER_MODE_FP32X) {
         // both planes share a stage: the ring doubles, so FP32X uses the two configurations that still fit 160 KiB
@@ -606,7 +606,6 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         case CFG_LN512_M32: return launch_cfg<1, 4, 2, 8, 64, 2, true>(a, s);   // 32 x 512 tile, 4 waves of 32x128
         case CFG_128x64:  return launch_cfg<4, 1, 2, 4, 64, 2, false>(a, s);    // 4 waves of 32x64: a wave owns a whole 64-column stat group
         case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
-        case CFG_256x256_W4: return launch_cfg<2, 2, 8, 8, 64, 2, false>(a, s);  // 4 waves of 128x128: 2/3 of the LDS reads per FLOP
         case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
         default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
     }

@@ -52,7 +52,8 @@ __global__ void logmel_init_kernel(double2* tw) {
 // 201 of 256 lanes.  Wave w owns the 16-bin column blocks w, w+4, w+8(, w+12); one 16-byte load of (cos, -sin) feeds
 // the re and the im MFMA of a block.  Operand lane maps (MI355X guide): A[i = lane & 15][k = lane >> 4],
 // B[k = lane >> 4][j = lane & 15], D[row = (lane >> 4) + 4 r][col = lane & 15].
-__global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ wav, const int64_t* __restrict__ offs,
+// three waves per SIMD (168 VGPRs, 16 spilled; 52 KB of LDS per block): measured 209 us per 8 x 30 s against 237 us at two
+__global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict__ wav, const int64_t* __restrict__ offs,
                                                      const float* __restrict__ mel, int n_mels,
                                                      const double2* __restrict__ tw, float* __restrict__ out,
                                                      float* __restrict__ bmax) {

@@ -121,11 +121,11 @@ def test_gemm_integer_exact(L, mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 256), (257, 264, 64), (1030, 128, 640), (300, 136, 128), (140, 256, 192), (129, 8, 320)])
 def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
-    """128x128 / 256x128 / 256x256 (8 waves) / 256x256 (4 waves of 128x128) block tiles (2- and 3-stage rings; K = 64..640
-    covers every ring fill / drain length) forced through tile_cfg."""
+    """128x128 / 256x128 / 256x256 block tiles (2- and 3-stage rings; K = 64..640 covers every ring fill / drain
+    length) forced through tile_cfg."""
     g = torch.Generator().manual_seed(M + N + cfg)
     A = torch.randint(-3, 4, (M, K), generator=g).float()
     W = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()

@@ -23,7 +23,7 @@ for name, M, N, K, gelu, res, act_out in SHAPES:
     of = torch.empty(M, N, device=DEV)
     oa = torch.empty(planes, M, N, dtype=torch.bfloat16, device=DEV)
     res_ms = {}
-    for cfg in (1, 2, 3, 4):
+    for cfg in (1, 2, 3):
         g = L.GemmArgs()
         g.A, g.a_plane_stride, g.lda = A.data_ptr(), M * K, K
         g.W, g.w_plane_stride = W.data_ptr(), N * K
