@@ -238,11 +238,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU.  (local_rank % device_count is the identity on a full node; with SER_DIST_BACKEND=gloo it lets the
+    # multi-rank control flow be rehearsed by N processes on ONE GPU, where RCCL would refuse two ranks on a device.)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     from interspeech_ser_amd import dist as D
-    D.init("nccl" if world > 1 else None, device)
+    D.init((os.environ.get("SER_DIST_BACKEND") or "nccl") if world > 1 else None, device)
 
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import build_encoder
