@@ -32,9 +32,12 @@ python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "micros
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_sq.err || exit 1
 python3 tools/pmc_sq_summary.py $OUT/pmc_sq profiles/$TAG
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_l2.err || exit 1
+python3 tools/pmc_l2_summary.py $OUT/pmc_l2 profiles/$TAG
 # Whisper front end alone against HBM bytes (FETCH/WRITE of the logmel kernels come out of the per-kernel CSV)
 WPMC="--steps 1 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS --ssl_type openai/whisper-large-v3 --seconds 30"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_fetch -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_write -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_write.err || exit 1
 python3 tools/pmc_summary.py $OUT/wpmc_fetch $OUT/wpmc_write profiles/${TAG}_whisper "openai/whisper-large-v3|bf16|batch=16x30s|groups=2"
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/      # profiles/ itself does not travel back
 echo done
