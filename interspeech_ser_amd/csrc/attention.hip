@@ -62,8 +62,11 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 // and the bias path does not zero accumulators it is about to overwrite.
 // NWV waves (x 32 queries) per block.  8 waves halve the K/V global->LDS traffic and the bias-row copies per query:
 // used for bf16 head dims <= 64 once an utterance has more than one 128-query tile.
+#ifndef SER_ATTN_MINW
+#define SER_ATTN_MINW 2          // waves per SIMD the register allocation must leave room for (A/B knob at build time)
+#endif
 template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : 2))
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : ((DHP == 64 && MODE != SER_MODE_FP32X) ? SER_ATTN_MINW : 2)))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
     constexpr int NP = (MODE == SER_MODE_FP32X) ? 2 : 1;
@@ -107,6 +110,16 @@ void attention_kernel(const AttnParams p) {
     // ---- staging helpers: thread owns chunks c = tid + i*256 of the [64 keys][CPR] tile --------
     u32x4 stg[NP][2][NCH];
     const bool padded = (dh != DHP);
+    // per-thread source of its chunks in key tile 0; a full tile kt is that plus kt * 64 rows (one 64-bit add per chunk
+    // instead of the clamp + 64-bit multiply the ragged last tile needs: ~25 VALU per tile off the loop)
+    const unsigned short* src0[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT;
+        const int key = c / CPR, ch = c - key * CPR;
+        src0[i] = p.qkv + (int64_t)(row0 + key) * p.ld + h * dh + (ch * 8 < dh ? ch * 8 : 0);
+    }
+    const int64_t tile_step = (int64_t)ABKV * p.ld;
     auto stage_load = [&](int kt, bool masked) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -115,8 +128,8 @@ void attention_kernel(const AttnParams p) {
             const int kg = kt * ABKV + key;
             // branch-free: always load from a valid address, zero by select (keys >= T, pad columns >= dh)
             const bool ok = (kg < TK) && (ch * 8 < dh);
-            const unsigned short* src = p.qkv + (int64_t)(row0 + (kg < T ? kg : T - 1)) * p.ld + h * dh
-                                      + (ch * 8 < dh ? ch * 8 : 0);
+            const unsigned short* src = (kg < T || !masked) ? src0[i] + kt * tile_step
+                                                            : src0[i] + (int64_t)(T - 1 - key) * p.ld;
             const unsigned int keep = ok ? 0xffffffffu : 0u;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {

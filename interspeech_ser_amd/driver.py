@@ -49,11 +49,16 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
     p.add_argument("--batch_size", type=int, default=16)
     p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "f16", "bf16"],
                    help="fp32x: fp32-grade results (~2e-5 of the fp32 reference); f16: fp32x conv stem + fp16 encoder "
-                        "layers (within the 1e-3 parity gate, ~1.7x faster); bf16: fastest (~1e-2)")
+                        "layers (within the 1e-3 parity gate, ~2x faster); bf16: fastest (~1e-2).  Limits: WavLM utterances up "
+                        "to ~2 min (the relative-position bias window of one utterance must fit the 160 KiB LDS; longer "
+                        "files are reported per file and skipped), utterances of at least 400 samples")
     p.add_argument("--checkpoint", type=str, default="",
                    help="local *.safetensors / pytorch_model.bin (or directory); default: HF cache lookup, "
                         "else seeded synthetic weights")
     p.add_argument("--skip_existing", action="store_true")
+    p.add_argument("--save_format", type=str, default="pt", choices=["pt", "npy"],
+                   help="pt (default): what the reference writes and its heads read (torch.save of a [T, D] float32 tensor); "
+                        "npy: the same array as <name>.npy for consumers without torch")
     p.add_argument("--resample", action="store_true",
                    help="accept non-16 kHz wav files through a polyphase resampler (parity with librosa's soxr_hq unpinned)")
     p.add_argument("--lora_alpha", type=float, default=16.0,
@@ -271,7 +276,8 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
     sizes = [os.path.getsize(p) for p in paths]
     mine = shard_files(paths, sizes, rank, world)
     if args.skip_existing:
-        mine = [p for p in mine if not os.path.isfile(feature_path(args.save_path, p))]
+        ext = ".npy" if args.save_format == "npy" else ".pt"
+        mine = [p for p in mine if not os.path.isfile(feature_path(args.save_path, p)[:-3] + ext)]
     batches = make_batches(mine, max(1, args.batch_size))
 
     def decode(path):
@@ -283,7 +289,11 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
     def write(item):
         path, feats = item
         try:
-            save_feature(feats, feature_path(args.save_path, path))
+            out = feature_path(args.save_path, path)
+            if args.save_format == "npy":
+                np.save(out[:-3] + ".npy", feats.numpy())
+            else:
+                save_feature(feats, out)
         except Exception as e:                            # noqa: BLE001
             print(f"Failed to process {path}: {e}")
 
@@ -401,7 +411,7 @@ def build_text_parser() -> argparse.ArgumentParser:
     p.add_argument("--df_path", type=str, default="./")
     p.add_argument("--save_path", type=str, default="./")
     p.add_argument("--num_workers", type=int, default=4)
-    p.add_argument("--max_len", type=int, default=80)
+    p.add_argument("--max_len", type=int, default=80, help="tokens per text (DeBERTa checkpoints: at most 128)")
     p.add_argument("--use_average", type=str, default="n")
     p.add_argument("--batch_size", type=int, default=64)
     p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "bf16"])
@@ -474,6 +484,9 @@ def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None, family: str
         geo = C.geometry_for(args.roberta_type)
         if geo.family != family:
             raise OSError(f"{args.roberta_type} is not a {family} encoder")
+        if family == C.FAMILY_DEBERTA and args.max_len > 128:
+            raise OSError(f"--max_len {args.max_len}: the DeBERTa path handles at most 128 tokens per text "
+                          f"(the reference uses 80)")
         if tokenize is None:
             tokenize = hf_tokenize_fn(args.tokenizer_path or args.roberta_type, args.max_len, family)
         sd, err = None, ""

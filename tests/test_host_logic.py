@@ -295,3 +295,36 @@ def test_pt_writer_threads_do_not_interfere(tmp_path):
         list(ex.map(lambda it: frontend.save_feature(it[1], str(tmp_path / f"u{it[0]}.pt")), enumerate(ts)))
     for i, t in enumerate(ts):
         assert torch.equal(torch.load(str(tmp_path / f"u{i}.pt")), t)
+
+
+def test_driver_save_format_npy_and_bad_layer_report(tmp_path, capsys):
+    """The driver around a stubbed model call (no GPU): --save_format npy writes <name>.npy holding the same [T, D] float32
+    array, and an out-of-range --n_layer is reported per file the way ``hidden_states[N]`` fails in the reference, not raised."""
+    class Stub:
+        pipelined = False
+
+        def __init__(self, args, whisper, device):
+            self.geo = C.TINY_WAVLM
+            self.weight_source = "stub"
+
+        def extract(self, waves, layer_index):
+            return [torch.full((self.geo.frames_for(len(w)), 4), float(layer_index)) for w in waves]
+
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    rng = np.random.default_rng(0)
+    for i, n in enumerate((4000, 6000, 9000)):
+        write_wav(wav_dir / f"u{i}.wav", 0.1 * rng.standard_normal(n))
+    out = tmp_path / "npy"
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--save_format", "npy", "--n_layer", "1"],
+                       whisper=False, extractor_factory=Stub) == 0
+    assert sorted(os.listdir(out)) == ["u0.npy", "u1.npy", "u2.npy"]
+    a = np.load(out / "u1.npy")
+    assert a.dtype == np.float32 and a.shape == (C.TINY_WAVLM.frames_for(6000), 4) and float(a[0, 0]) == 1.0
+    capsys.readouterr()
+    out2 = tmp_path / "bad"
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out2), "--n_layer", "7"], whisper=False,
+                       extractor_factory=Stub) == 0
+    log = capsys.readouterr().out
+    assert log.count("tuple index out of range") == 3 and os.listdir(out2) == []
+    assert "SER_RUN " in log
