@@ -192,6 +192,10 @@ int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, 
                   int H, int dh, float scale, int mode,
                   int gate_col, const float* gru_const /*[H]*/,
                   const int32_t* key_lens /*[B] or NULL: keys >= key_lens[b] are padding (RoBERTa attention_mask)*/,
+                  const float* bias2d /*[B][H][max_frames][bias2d_ld] fp32 dense additive bias in the exp2 domain, or NULL
+                                        (DeBERTa, from ser_deberta_bias): uniform-length batches, q pre-scaled, dh <= 64; padded
+                                        query rows (q >= key_lens[b]) then come out as the uniform average of all value rows*/,
+                  int64_t bias2d_ld,
                   void* stream);
 
 /* next row 8f-1 (text side): RoBERTa embeddings word[id] + position[cumsum(non-pad)] + token_type[0] -> LayerNorm
@@ -226,10 +230,17 @@ int ser_pack_act(const float* x, int B, int C, int T, int halo, void* out, int64
  * c2p_col / p2c_col: [2T-1] int32, column inside that window for signed distance d at index d + T - 1
  * (c2p reads c2p[q][c2p_col[q-k]], p2c reads p2c[k][p2c_col[k-q]]; the log-bucket map is built by the host).
  * A (query, key) pair counts only if both are real tokens (t < key_lens[b]); a padded query row comes out as the
- * uniform average of all T value rows, as HF's masked_fill(finfo.min) + softmax gives.  T <= 128, dh <= 64. */
+ * uniform average of all T value rows, as HF's masked_fill(finfo.min) + softmax gives.  T <= 128, dh <= 64.
+ * (ser_deberta_attention is the one-thread-per-query statement of the op, kept as the kernel-level reference; the encoder
+ * runs ser_deberta_bias + ser_attention(bias2d), which has no 128-token limit.) */
 int ser_embed_ln_masked(const int32_t* ids, const float* word_emb, const float* ln_g, const float* ln_b, float eps,
                         const int32_t* key_lens, float* out_f32, void* out_act, int64_t out_plane_stride,
                         int mode, int B, int T, int D, void* stream);
+/* Dense disentangled-attention bias for ser_attention's bias2d argument (the matrix-core path the DeBERTa encoder uses):
+ *   out[b][h][q][k] = c2p[q][c2p_col[q-k]] + p2c_scale * p2c[k][p2c_col[k-q]]   for q, k < key_lens[b], else 0;   row pitch ld.
+ * c2p is expected from a q that already carries the score scale (ser_gemm col_scale), p2c from the plain k. */
+int ser_deberta_bias(const float* c2p, const float* p2c, int64_t ldp, int Nr, const int32_t* c2p_col, const int32_t* p2c_col,
+                     const int32_t* key_lens, float* out, int64_t ld, int B, int T, int H, float p2c_scale, void* stream);
 int ser_deberta_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
                           const float* c2p, const float* p2c, int64_t ldp, int Nr, const int32_t* c2p_col,
                           const int32_t* p2c_col, const int32_t* key_lens, void* out, int64_t ldo,
@@ -264,6 +275,7 @@ typedef struct ser_attention_args {
     void* out; int64_t ldo; int64_t out_plane_stride;
     int32_t H, dh; float scale; int32_t mode; int32_t gate_col, reserved0;
     const float* gru_const; const int32_t* key_lens;
+    const float* bias2d; int64_t bias2d_ld;
 } ser_attention_args;
 
 typedef struct ser_layernorm_args {

@@ -60,6 +60,7 @@ class AttentionArgs(C.Structure):
         ("H", C.c_int32), ("dh", C.c_int32), ("scale", c_float), ("mode", C.c_int32),
         ("gate_col", C.c_int32), ("reserved0", C.c_int32),
         ("gru_const", c_void_p), ("key_lens", c_void_p),
+        ("bias2d", c_void_p), ("bias2d_ld", c_i64),
     ]
 
 
@@ -134,7 +135,7 @@ _SIGNATURES = {
     "ser_wavlm_gate": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                c_int, c_void_p]),
     "ser_attention": (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                              c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                              c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ser_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                              c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ser_logmel_init": (c_int, [c_void_p, c_int, c_void_p]),
@@ -146,6 +147,8 @@ _SIGNATURES = {
                                     c_int, c_int, c_int, c_int, c_void_p]),
     "ser_deberta_attention": (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ser_deberta_bias": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int,
+                                 c_float, c_void_p]),
     "ser_run": (c_int, [c_void_p, C.c_int32, c_void_p, c_void_p]),
     "ser_ragged_index": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64, c_void_p]),
     "ser_workspace_bytes": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

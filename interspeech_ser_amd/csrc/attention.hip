@@ -47,6 +47,12 @@ struct AttnParams {
     int H, dh, B, nq;
     int bias_stride;      // floats per shifted bias copy in LDS
     float scale;
+    // dense additive bias (DeBERTa's disentangled-attention terms, built by ser_deberta_bias): [B][H][T][b2d_ld] fp32 in the
+    // exp2 domain, zero where a pair is masked.  With it, padded QUERY rows (q >= key_lens[b]) follow HF's masked_fill(min) +
+    // softmax: every score equal -> the uniform average of all T value rows.
+    const float* bias2d;
+    int64_t b2d_ld;
+    int b2d_T;            // rows per (utterance, head) block of bias2d (= max_frames: uniform-length batches)
 };
 
 template <int DHP>
@@ -65,7 +71,8 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 #ifndef SER_ATTN_MINW
 #define SER_ATTN_MINW 2          // waves per SIMD the register allocation must leave room for (A/B knob at build time)
 #endif
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4>
+// B2D: dense additive bias from global memory instead of the relative-position table (needs PRE, excludes TBL).
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : ((DHP == 64 && MODE != SER_MODE_FP32X) ? SER_ATTN_MINW : 2)))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
@@ -98,7 +105,8 @@ void attention_kernel(const AttnParams p) {
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
     const int TK = p.key_lens ? p.key_lens[b] : T;               // attendable keys (== T for speech)
-    const int nkt = (TK + ABKV - 1) / ABKV;
+    const int TS = B2D ? T : TK;                                 // keys staged / visited (padded queries of B2D see all T)
+    const int nkt = (TS + ABKV - 1) / ABKV;
     // first relative-position slot any query of this block reads, moved down by 0..3 (possibly below 0: zero-filled) so
     // that T-1-jmin == 3 (mod 4).  Queries 4m..4m+3 of a quad then read the SAME aligned offset of the 4 shifted copies
     // (one 16-lane group of a ds_read_b128 = 4 quads x 4 copies = 16 distinct 4-bank slots); with any other residue a
@@ -127,7 +135,7 @@ void attention_kernel(const AttnParams p) {
             const int key = c / CPR, ch = c - key * CPR;
             const int kg = kt * ABKV + key;
             // branch-free: always load from a valid address, zero by select (keys >= T, pad columns >= dh)
-            const bool ok = (kg < TK) && (ch * 8 < dh);
+            const bool ok = (kg < TS) && (ch * 8 < dh);
             const unsigned short* src = (kg < T || !masked) ? src0[i] + kt * tile_step
                                                             : src0[i] + (int64_t)(T - 1 - key) * p.ld;
             const unsigned int keep = ok ? 0xffffffffu : 0u;
@@ -158,7 +166,9 @@ void attention_kernel(const AttnParams p) {
         }
     };
 
-    const int nfull = (TK & (ABKV - 1)) ? nkt - 1 : nkt;         // tiles without key padding
+    // tiles without key padding; with a dense bias every tile takes the per-element key check (real queries stop at TK,
+    // padded ones at T; 80-token problems: two tiles)
+    const int nfull = B2D ? 0 : ((TK & (ABKV - 1)) ? nkt - 1 : nkt);
     stage_load(0, padded || nfull == 0);
 
     // ---- Q fragments: lane holds Q[q][16*ks + 8*hh + j].  Requested here, with the gate inputs, so that their
@@ -174,7 +184,7 @@ void attention_kernel(const AttnParams p) {
             for (int ks = 0; ks < KS; ++ks) {
                 const int d = ks * 16 + hh * 8;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (d < dh) v = *(const u32x4*)(qrow + pl * p.plane + d);
+                if (d < dh && !(B2D && q >= TK)) v = *(const u32x4*)(qrow + pl * p.plane + d);      // padded query: all scores equal
                 qf[pl][ks] = __builtin_bit_cast(bf16x8, v);
             }
     }
@@ -217,6 +227,8 @@ void attention_kernel(const AttnParams p) {
         }
     }
 
+    const int klim = (B2D && q >= TK) ? T : TK;                   // keys this lane's query may attend to
+    const float* brow = B2D ? p.bias2d + ((int64_t)bh * p.b2d_T + qc) * p.b2d_ld : nullptr;
     const float c1 = p.scale * LOG2E;
     float gq2 = 0.f;
     if (TBL) {
@@ -266,6 +278,13 @@ void attention_kernel(const AttnParams p) {
                     for (int g4 = 0; g4 < 4; ++g4)
                         bvv[sub][g4] = *(const f32x4*)(bcopy + kt * ABKV + sub * 32 + 8 * g4 + 4 * hh);
             }
+            if (PRE && B2D) {                                        // rows are b2d_ld = a multiple of 64 floats long, zero padded
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        bvv[sub][g4] = *(const f32x4*)(brow + kt * ABKV + sub * 32 + 8 * g4 + 4 * hh);
+            }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const int key = sub * 32 + l31;
@@ -279,7 +298,7 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = (PRE && TBL) ? gq2 * bvv[sub][g4][r] : 0.f;
+                    for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = (PRE && TBL) ? gq2 * bvv[sub][g4][r] : ((PRE && B2D) ? bvv[sub][g4][r] : 0.f);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)                          // the two key halves are independent chains
 #pragma unroll
@@ -295,6 +314,13 @@ void attention_kernel(const AttnParams p) {
                         const f32x4 bv = *(const f32x4*)(bcopy + kb);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = gq2 * bv[r];
+                    }
+                } else if (PRE && B2D) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 bv = *(const f32x4*)(brow + kt * ABKV + sub * 32 + 8 * g4 + 4 * hh);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = bv[r];
                     }
                 } else {
 #pragma unroll
@@ -351,7 +377,7 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = PRE ? st[sub][4 * g4 + r] : fmaf(st[sub][4 * g4 + r], c1, gq2 * bv[r]);
-                    if (RAGGED) v = (kb + r < TK) ? v : -INFINITY;
+                    if (RAGGED) v = (kb + r < klim) ? v : -INFINITY;
                     st[sub][4 * g4 + r] = v;
                     mloc = fmaxf(mloc, v);
                 }
@@ -449,9 +475,9 @@ void attention_kernel(const AttnParams p) {
     }
 }
 
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4>
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV>;
+    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D>;
     static bool ready = false;
     if (lds > 65536 && !ready) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -466,7 +492,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
                              const int32_t* frame_offs, int B, int max_frames, const float* table, int table_T,
                              const float* gate, void* out, int64_t ldo, int64_t out_plane_stride, int H, int dh,
                              float scale, int mode, int gate_col, const float* gru_const, const int32_t* key_lens,
-                             void* stream) {
+                             const float* bias2d, int64_t bias2d_ld, void* stream) {
     if (!qkv || !frame_offs || !out) return ser_fail(-1, "ser_attention: null pointer");
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
@@ -477,6 +503,12 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     if (gate && gru_const) return ser_fail(-9, "ser_attention: give gate[] or gru_const, not both");
     if (gru_const && (gate_col < 0 || (gate_col % 2))) return ser_fail(-10, "ser_attention: bad gate_col %d", gate_col);
     if (table && table_T < max_frames) return ser_fail(-7, "ser_attention: bias table built for T=%d < max_frames=%d", table_T, max_frames);
+    if (bias2d) {
+        if (table || !key_lens || scale > 0.f || dh > 64 || mode == SER_MODE_FP16)
+            return ser_fail(-11, "ser_attention: bias2d needs key_lens, a pre-scaled q (scale <= 0), dh <= 64, no table, bf16 / fp32x");
+        if (bias2d_ld < max_frames || (bias2d_ld % ABKV))
+            return ser_fail(-12, "ser_attention: bias2d_ld=%lld must be a multiple of %d and >= max_frames", (long long)bias2d_ld, ABKV);
+    }
     const int dhp = dh <= 64 ? 64 : 128;
     const int np = mode == SER_MODE_FP32X ? 2 : 1;
     // 8-wave blocks: -1.1 us per launch in isolation (24.4 -> 23.3 us at 8 x 499 frames), +1.2 % on the real step
@@ -501,12 +533,16 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     p.gru_const = gru_const; p.gate_col = gate_col;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
+    p.bias2d = bias2d; p.b2d_ld = bias2d_ld; p.b2d_T = max_frames;
     p.B = B; p.nq = (max_frames + 32 * nwv - 1) / (32 * nwv);
     dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * p.nq), 1, 1);
     hipStream_t s = (hipStream_t)stream;
     const bool pre = scale <= 0.f;
 #define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
                               : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
+    if (bias2d)
+        return mode == SER_MODE_FP32X ? launch_attention<64, SER_MODE_FP32X, true, false, 4, true>(p, grid, lds, s)
+                                      : launch_attention<64, SER_MODE_BF16, true, false, 4, true>(p, grid, lds, s);
     if (dhp == 64 && mode == SER_MODE_BF16 && nwv == 8)
         return pre ? (table ? launch_attention<64, SER_MODE_BF16, true, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, true, false, 8>(p, grid, lds, s))
                    : (table ? launch_attention<64, SER_MODE_BF16, false, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, false, false, 8>(p, grid, lds, s));

@@ -160,6 +160,49 @@ __global__ __launch_bounds__(128) void deberta_attention_kernel(
             store_act4<MODE>(orow + 4 * d4, out_plane, o[d4][0] * inv, o[d4][1] * inv, o[d4][2] * inv, o[d4][3] * inv);
 }
 
+// ------------------------------------------------------------------------------------- dense bias
+// bias[b][h][q][k] = c2p[q][ci[q-k]] + p2c_scale * p2c[k][pi[k-q]]  for real tokens q, k < key_lens[b], else 0
+// (the attention kernel masks the keys a real query may not see and gives a padded query equal scores everywhere).
+// c2p comes from the pre-scaled q, so only the position -> content term needs the score scale.  Thread = 4 consecutive keys.
+__global__ __launch_bounds__(256) void deberta_bias_kernel(const float* __restrict__ c2p, const float* __restrict__ p2c,
+                                                           int64_t ldp, int Nr, const int32_t* __restrict__ ci,
+                                                           const int32_t* __restrict__ pi, const int32_t* __restrict__ key_lens,
+                                                           float* __restrict__ out, int64_t ld, int T, int H, float p2c_scale,
+                                                           int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k4 = (int)(i % (ld / 4)) * 4;
+    const int64_t r = i / (ld / 4);
+    const int q = (int)(r % T);
+    const int64_t bh = r / T;
+    const int h = (int)(bh % H), b = (int)(bh / H);
+    const int len = key_lens[b];
+    const int64_t row0 = (int64_t)b * T;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < len) {
+        const float* c2p_row = c2p + (row0 + q) * ldp + (int64_t)h * Nr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k4 + j;
+            if (k < len)
+                v[j] = c2p_row[ci[q - k + T - 1]] + p2c_scale * p2c[(row0 + k) * ldp + (int64_t)h * Nr + pi[k - q + T - 1]];
+        }
+    }
+    *(f32x4*)(out + r * ld + k4) = v;
+}
+
+extern "C" int ser_deberta_bias(const float* c2p, const float* p2c, int64_t ldp, int Nr, const int32_t* c2p_col,
+                                const int32_t* p2c_col, const int32_t* key_lens, float* out, int64_t ld, int B, int T, int H,
+                                float p2c_scale, void* stream) {
+    if (!c2p || !p2c || !c2p_col || !p2c_col || !key_lens || !out) return ser_fail(-1, "ser_deberta_bias: null pointer");
+    if (B <= 0 || H <= 0 || T <= 0 || Nr <= 0 || ldp < (int64_t)H * Nr) return ser_fail(-2, "ser_deberta_bias: bad shape");
+    if (ld < T || (ld % 4)) return ser_fail(-3, "ser_deberta_bias: ld=%lld must be a multiple of 4 and >= T", (long long)ld);
+    const int64_t total = (int64_t)B * H * T * (ld / 4);
+    hipLaunchKernelGGL(deberta_bias_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c2p, p2c, ldp,
+                       Nr, c2p_col, p2c_col, key_lens, out, ld, T, H, p2c_scale, total);
+    return ser_check_launch("ser_deberta_bias");
+}
+
 extern "C" int ser_deberta_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, int k_col, int v_col,
                                      const float* c2p, const float* p2c, int64_t ldp, int Nr, const int32_t* c2p_col,
                                      const int32_t* p2c_col, const int32_t* key_lens, void* out, int64_t ldo,

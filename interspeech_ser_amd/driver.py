@@ -411,7 +411,7 @@ def build_text_parser() -> argparse.ArgumentParser:
     p.add_argument("--df_path", type=str, default="./")
     p.add_argument("--save_path", type=str, default="./")
     p.add_argument("--num_workers", type=int, default=4)
-    p.add_argument("--max_len", type=int, default=80, help="tokens per text (DeBERTa checkpoints: at most 128)")
+    p.add_argument("--max_len", type=int, default=80, help="tokens per text (at most 512, the models' position range)")
     p.add_argument("--use_average", type=str, default="n")
     p.add_argument("--batch_size", type=int, default=64)
     p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "bf16"])
@@ -484,9 +484,8 @@ def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None, family: str
         geo = C.geometry_for(args.roberta_type)
         if geo.family != family:
             raise OSError(f"{args.roberta_type} is not a {family} encoder")
-        if family == C.FAMILY_DEBERTA and args.max_len > 128:
-            raise OSError(f"--max_len {args.max_len}: the DeBERTa path handles at most 128 tokens per text "
-                          f"(the reference uses 80)")
+        if args.max_len > 512:
+            raise OSError(f"--max_len {args.max_len}: these text encoders have 512 positions (the reference uses 80)")
         if tokenize is None:
             tokenize = hf_tokenize_fn(args.tokenizer_path or args.roberta_type, args.max_len, family)
         sd, err = None, ""

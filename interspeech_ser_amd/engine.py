@@ -315,7 +315,7 @@ class _EncoderBase:
                                  shift.data_ptr(), self.mode, rows, D, self._s()), "ser_row_center")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
-                   gru_const=None, key_lens=None):
+                   gru_const=None, key_lens=None, bias2d=None):
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
         rec = self._rec
         if rec is not None:
@@ -327,11 +327,13 @@ class _EncoderBase:
             a.out, a.ldo, a.out_plane_stride = out.ptr, out.cols, out.plane_stride
             a.H, a.dh, a.scale, a.mode, a.gate_col = H, dh, -1.0, self.mode, 3 * D        # q is pre-scaled
             a.gru_const, a.key_lens = _ptr(gru_const), _ptr(key_lens)
+            a.bias2d, a.bias2d_ld = _ptr(bias2d), (0 if bias2d is None else bias2d.shape[-1])
             rec.commit(_lib.OP_ATTENTION, a, B=B, max_frames=max_frames, table_T=table_T)
             return
         check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
                                 max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
-                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _ptr(key_lens), self._s()),   # q is pre-scaled
+                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _ptr(key_lens), _ptr(bias2d),
+                                0 if bias2d is None else bias2d.shape[-1], self._s()),   # q is pre-scaled
               "ser_attention")
 
     @staticmethod
@@ -1138,6 +1140,8 @@ class DebertaEncoder(_EncoderBase):
         pl["qkv"], pl["ctx"], pl["ffn"] = self._new_act(M, 3 * D), self._new_act(M, D), self._new_act(M, Fd)
         pl["c2p"] = torch.empty((M, geo.heads * win["Nr"]), dtype=torch.float32, device=dev)
         pl["p2c"] = torch.empty((M, geo.heads * win["Nr"]), dtype=torch.float32, device=dev)
+        pl["frame_offs"] = torch.tensor(pl["frame_offs_host"], dtype=torch.int32, device=dev)
+        pl["bias2d"] = torch.zeros((B, geo.heads, T, (T + 63) // 64 * 64), dtype=torch.float32, device=dev)   # dense c2p + p2c bias
         pl["tmp"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         if len(self._cache) >= 4:
@@ -1150,8 +1154,6 @@ class DebertaEncoder(_EncoderBase):
         B, T = input_ids.shape
         if attention_mask.shape != input_ids.shape:
             raise ValueError("attention_mask must have the shape of input_ids")
-        if T > 128:
-            raise ValueError("DeBERTa path: at most 128 tokens per sequence (the reference uses max_len = 80)")
         mask = attention_mask.to(torch.int64).cpu()
         klen = mask.sum(dim=1)
         if not torch.equal(mask, (torch.arange(T)[None, :] < klen[:, None]).to(torch.int64)) or int(klen.min()) < 1:
@@ -1172,19 +1174,26 @@ class DebertaEncoder(_EncoderBase):
         check(lib.ser_embed_ln_masked(ids.data_ptr(), self.wemb.data_ptr(), self.emb_ln[0].data_ptr(), self.emb_ln[1].data_ptr(),
                                       float(geo.layer_norm_eps), key_lens.data_ptr(), states[0].data_ptr(), xa.ptr, xa.plane_stride,
                                       self.mode, B, T, D, st), "ser_embed_ln_masked")
+        # scores run in the exp2 domain: q leaves the projection multiplied by (3 dh)^-0.5 * log2(e), so the content term and the
+        # content -> position term (a product with q) arrive scaled; the position -> content term (a product with k) is scaled
+        # by ser_deberta_bias.  (HF: (Qc Kc^T + c2p + p2c) / sqrt(3 dh), modeling_deberta_v2.py DisentangledSelfAttention.)
+        s2 = (3.0 * dh) ** -0.5 * 1.4426950408889634
+        bias2d = pl["bias2d"]
         for i, lay in enumerate(self.layers):
             x = states[i]
             pos_k, pos_q = win["layers"][i]
-            self._gemm(xa, lay["qkv"], M, out_act=qkv)
+            self._gemm(xa, lay["qkv"], M, out_act=qkv, col_scale=s2, col_scale_end=D)
             # content -> position and position -> content terms: one grouped GEMM each (group = head, K = dh)
             self._gemm(qkv, pos_k, M, groups=H, a_group_stride=dh, w_group_stride=Nr * dh, c_group_stride=Nr, N=Nr, K=dh,
                        out_f32=pl["c2p"], ldo_f32=H * Nr)
             self._gemm(qkv, pos_q, M, groups=H, a_group_stride=dh, w_group_stride=Nr * dh, c_group_stride=Nr, N=Nr, K=dh,
                        a_ptr_offset=2 * D, out_f32=pl["p2c"], ldo_f32=H * Nr)
-            check(lib.ser_deberta_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, pl["c2p"].data_ptr(),
-                                            pl["p2c"].data_ptr(), H * Nr, Nr, win["c2p_col"].data_ptr(), win["p2c_col"].data_ptr(),
-                                            key_lens.data_ptr(), pl["ctx"].ptr, pl["ctx"].cols, pl["ctx"].plane_stride,
-                                            B, T, H, dh, self.mode, st), "ser_deberta_attention")
+            # dense bias of every (sequence, head) from the two gathers, then the matrix-core attention kernel of the speech
+            # encoders with it (the 80-token VALU kernel ser_deberta_attention was a third of the step)
+            check(lib.ser_deberta_bias(pl["c2p"].data_ptr(), pl["p2c"].data_ptr(), H * Nr, Nr, win["c2p_col"].data_ptr(),
+                                       win["p2c_col"].data_ptr(), key_lens.data_ptr(), bias2d.data_ptr(), bias2d.shape[-1],
+                                       B, T, H, float(s2), st), "ser_deberta_bias")
+            self._attention(qkv, pl["frame_offs"], B, T, pl["ctx"], key_lens=key_lens, bias2d=bias2d)
             self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["tmp"], ldo_f32=D)
             self._layernorm(pl["tmp"], D, lay["ln1"], M, D, out_f32=pl["h"], out_act=pl["ha"])
             self._gemm(pl["ha"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])

@@ -57,7 +57,7 @@ def test_argument_errors_are_reported_not_raised(built_library):
     assert _lib.lib.ser_gemm(ctypes.byref(g), None) < 0
     assert b"ser_gemm" in _lib.lib.ser_last_error()
     assert _lib.lib.ser_layernorm(None, 0, None, None, 1e-5, 0, None, 0, None, 0, 0, 1, 1, 8, None) < 0
-    assert _lib.lib.ser_attention(None, 0, 0, 0, 0, 0, None, 1, 1, None, 0, None, None, 0, 0, 1, 64, 0.125, 1, 0, None, None, None) < 0
+    assert _lib.lib.ser_attention(None, 0, 0, 0, 0, 0, None, 1, 1, None, 0, None, None, 0, 0, 1, 64, 0.125, 1, 0, None, None, None, 0, None) < 0
     assert _lib.lib.ser_workspace_bytes(_lib.WS_LOGMEL, 4, 0, 0, 0, 1) == 4 * 1024 + 400 * 208 * 16 + 400 * 4
 
 

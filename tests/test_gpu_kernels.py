@@ -562,7 +562,7 @@ def test_attention(L, mode, dh, H, bias):
     gd = gate.to(DEV) if bias else None
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
                                 td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
-                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, None, stream()))
+                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, None, None, 0, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < mode_tol(mode, 3e-2, 1e-4), err
@@ -598,7 +598,7 @@ def test_attention_fused_gate_columns(L, mode):
     foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
     td, cd = table.to(DEV), cst.to(DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), ld, M * ld, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax, td.data_ptr(), Tmax,
-                                None, out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 3 * D, cd.data_ptr(), None, stream()))
+                                None, out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 3 * D, cd.data_ptr(), None, None, 0, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < mode_tol(mode, 3e-2, 1e-4), err
@@ -638,7 +638,7 @@ def test_attention_prescaled_q(L, mode, dh, bias):
     gd = gate.to(DEV) if bias else None
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
                                 td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
-                                out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, None, stream()))
+                                out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, None, None, 0, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < mode_tol(mode, 3e-2, 1e-4), err
@@ -684,7 +684,7 @@ def test_attention_key_lengths(L, mode):
     foffs = torch.arange(0, M + 1, T, dtype=torch.int32, device=DEV)
     kl = torch.tensor(klens, dtype=torch.int32, device=DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), B, T, None, 0, None,
-                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, kl.data_ptr(), stream()))
+                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0, None, kl.data_ptr(), None, 0, stream()))
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
     assert err < mode_tol(mode, 3e-2, 1e-4), err
@@ -727,7 +727,7 @@ def test_attention_online_softmax_rescale(L):
     out = torch.zeros(2, T, dh, dtype=torch.bfloat16, device=DEV)
     foffs = torch.tensor([0, T], dtype=torch.int32, device=DEV)
     L.check(L.lib.ser_attention(qa.data_ptr(), 3 * dh, T * 3 * dh, 0, dh, 2 * dh, foffs.data_ptr(), 1, T, None, 0, None,
-                                out.data_ptr(), dh, T * dh, H, dh, dh ** -0.5, 2, 0, None, None, stream()))
+                                out.data_ptr(), dh, T * dh, H, dh, dh ** -0.5, 2, 0, None, None, None, 0, stream()))
     torch.cuda.synchronize()
     assert (act_value(out).cpu().double() - ref).abs().max().item() < 1e-4
 
@@ -798,3 +798,68 @@ def test_gemm_deep_k_dispatch_is_exact(L):
     bias = torch.randint(-4, 5, (N,), generator=g).float()
     out, _ = run_gemm(L, to_act(A, 1), to_act(W, 1), M, N, K, 1, bias=bias.to(DEV))
     assert torch.equal(out.cpu().double(), A.double() @ W.double().T + bias.double())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("T", [80, 200])
+def test_deberta_dense_bias_attention(L, mode, T):
+    """DeBERTa's disentangled attention on the matrix cores: ser_deberta_bias (dense c2p + p2c bias per (sequence, head))
+    + ser_attention(bias2d) against an fp64 statement of softmax((Qc Kc^T + c2p + p2c) / sqrt(3 dh)) V with HF's both-token
+    mask (a padded query row = the uniform average of all T value rows), and -- at T <= 128 -- against the
+    one-thread-per-query kernel ser_deberta_attention it replaces on the encoder path.  T = 200 has no counterpart there."""
+    B, H, dh, Nr = 3, 2, 64, 40
+    D, M = H * dh, B * T
+    g = torch.Generator().manual_seed(T + mode)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    lens = [T, max(1, T // 3), 5][:B]
+    c2p = torch.randn(M, H * Nr, generator=g) * 0.5
+    p2c = torch.randn(M, H * Nr, generator=g) * 0.5
+    ci = torch.randint(0, Nr, (2 * T - 1,), generator=g, dtype=torch.int32)
+    pi = torch.randint(0, Nr, (2 * T - 1,), generator=g, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(3.0 * dh)
+    s2 = scale * 1.4426950408889634
+    qa_raw = to_act(qkv, mode)
+    qv = act_value(qa_raw).cpu().double()
+    ref = torch.empty(M, D, dtype=torch.float64)
+    idx = torch.arange(T)
+    for b in range(B):
+        n = lens[b]
+        blk = qv[b * T:(b + 1) * T]
+        for h in range(H):
+            q, k, v = (blk[:, i * D + h * dh: i * D + (h + 1) * dh] for i in range(3))
+            cq = c2p[b * T:(b + 1) * T, h * Nr:(h + 1) * Nr].double()
+            pk = p2c[b * T:(b + 1) * T, h * Nr:(h + 1) * Nr].double()
+            s = q @ k.T
+            s = s + torch.gather(cq, 1, ci[(idx[:, None] - idx[None, :]) + T - 1].long())                       # c2p[q][ci[q-k]]
+            s = s + torch.gather(pk, 1, pi[(idx[:, None] - idx[None, :]) + T - 1].long()).T                     # p2c[k][pi[k-q]]
+            s = s * scale
+            real = (idx[:, None] < n) & (idx[None, :] < n)
+            s = torch.where(real, s, torch.full_like(s, torch.finfo(torch.float32).min))
+            ref[b * T:(b + 1) * T, h * dh:(h + 1) * dh] = torch.softmax(s, dim=-1) @ v
+    planes = 2 if mode == 2 else 1
+    kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    cid, pid = ci.to(DEV), pi.to(DEV)
+    if T <= 128:
+        out_old = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib.ser_deberta_attention(qa_raw.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, c2p.to(DEV).data_ptr(), p2c.to(DEV).data_ptr(),
+                                            H * Nr, Nr, cid.data_ptr(), pid.data_ptr(), kl.data_ptr(), out_old.data_ptr(), D, M * D,
+                                            B, T, H, dh, mode, stream()), "ser_deberta_attention")
+        torch.cuda.synchronize()
+        assert (act_value(out_old).cpu().double() - ref).abs().max() < mode_tol(mode, 3e-2, 1e-4)
+    # new path: q pre-scaled (as the QKV GEMM's col_scale does), c2p from that q
+    qkv_s = qv.clone().float()
+    qkv_s[:, :D] *= s2
+    qa = to_act(qkv_s, mode)
+    ld = (T + 63) // 64 * 64
+    bias = torch.full((B, H, T, ld), float("nan"), device=DEV)
+    L.check(L.lib.ser_deberta_bias((c2p * s2).to(DEV).data_ptr(), p2c.to(DEV).data_ptr(), H * Nr, Nr, cid.data_ptr(), pid.data_ptr(),
+                                   kl.data_ptr(), bias.data_ptr(), ld, B, T, H, s2, stream()), "ser_deberta_bias")
+    out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
+    foffs = torch.arange(0, M + 1, T, dtype=torch.int32, device=DEV)
+    L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), B, T, None, 0, None,
+                                out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, kl.data_ptr(), bias.data_ptr(), ld, stream()),
+            "ser_attention")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(bias).all())
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < mode_tol(mode, 3e-2, 2e-4), err

@@ -20,7 +20,7 @@ for mode in (1, 2):
                 L.check(L.lib.ser_attention(qkv.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, offs.data_ptr(), B, T,
                                             table.data_ptr() if bias else None, T if bias else 0,
                                             gate.data_ptr() if bias else None, out.data_ptr(), D, M * D, H, dh,
-                                            dh ** -0.5, mode, 0, None, None, st))
+                                            dh ** -0.5, mode, 0, None, None, None, 0, st))
             for _ in range(3): run()
             ts = []
             for r in range(5):

@@ -13,5 +13,5 @@ table = torch.randn(H, 2 * T - 1, device=DEV); gate = torch.rand(M, H, device=DE
 for bias, scale in ((0, dh ** -0.5), (1, dh ** -0.5), (0, -1.0), (1, -1.0)):
     L.check(L.lib.ser_attention(qkv.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, offs.data_ptr(), B, T,
                                 table.data_ptr() if bias else None, T if bias else 0, gate.data_ptr() if bias else None,
-                                out.data_ptr(), D, M * D, H, dh, scale, 1, 0, None, None, st))
+                                out.data_ptr(), D, M * D, H, dh, scale, 1, 0, None, None, None, 0, st))
     torch.cuda.synchronize()

@@ -24,7 +24,7 @@ for mode in modes:
         def run():
             L.check(L.lib.ser_attention(qkv.data_ptr(), ld, M * ld, 0, D, 2 * D, offs.data_ptr(), B, T,
                                         table.data_ptr() if bias else None, T if bias else 0, None, out.data_ptr(), D, M * D, H, dh,
-                                        -1.0, mode, 3 * D, cst.data_ptr() if bias else None, None, st))
+                                        -1.0, mode, 3 * D, cst.data_ptr() if bias else None, None, None, 0, st))
         for _ in range(3):
             run()
         ts = []
