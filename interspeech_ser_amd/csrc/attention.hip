@@ -456,8 +456,12 @@ void attention_kernel(const AttnParams p) {
         }
     };
     // the key-padding select exists only in the last tile of a ragged utterance
-    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
-    if (nfull < nkt) tile(nkt - 1, std::true_type{});
+    if constexpr (B2D) {
+        for (int kt = 0; kt < nkt; ++kt) tile(kt, std::true_type{});      // every tile checks keys per element (see nfull)
+    } else {
+        for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+        if (nfull < nkt) tile(nkt - 1, std::true_type{});
+    }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane owns query q, 4 consecutive d per register quad
     if (q < T) {

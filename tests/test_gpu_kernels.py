@@ -839,9 +839,10 @@ def test_deberta_dense_bias_attention(L, mode, T):
     planes = 2 if mode == 2 else 1
     kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
     cid, pid = ci.to(DEV), pi.to(DEV)
+    c2p_d, p2c_d, c2p_s = c2p.to(DEV), p2c.to(DEV), (c2p * s2).to(DEV)            # keep the device copies alive across the launches
     if T <= 128:
         out_old = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
-        L.check(L.lib.ser_deberta_attention(qa_raw.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, c2p.to(DEV).data_ptr(), p2c.to(DEV).data_ptr(),
+        L.check(L.lib.ser_deberta_attention(qa_raw.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, c2p_d.data_ptr(), p2c_d.data_ptr(),
                                             H * Nr, Nr, cid.data_ptr(), pid.data_ptr(), kl.data_ptr(), out_old.data_ptr(), D, M * D,
                                             B, T, H, dh, mode, stream()), "ser_deberta_attention")
         torch.cuda.synchronize()
@@ -852,7 +853,7 @@ def test_deberta_dense_bias_attention(L, mode, T):
     qa = to_act(qkv_s, mode)
     ld = (T + 63) // 64 * 64
     bias = torch.full((B, H, T, ld), float("nan"), device=DEV)
-    L.check(L.lib.ser_deberta_bias((c2p * s2).to(DEV).data_ptr(), p2c.to(DEV).data_ptr(), H * Nr, Nr, cid.data_ptr(), pid.data_ptr(),
+    L.check(L.lib.ser_deberta_bias(c2p_s.data_ptr(), p2c_d.data_ptr(), H * Nr, Nr, cid.data_ptr(), pid.data_ptr(),
                                    kl.data_ptr(), bias.data_ptr(), ld, B, T, H, s2, stream()), "ser_deberta_bias")
     out = torch.zeros(planes, M, D, dtype=torch.bfloat16, device=DEV)
     foffs = torch.arange(0, M + 1, T, dtype=torch.int32, device=DEV)
