@@ -546,9 +546,12 @@ class SpeechEncoder(_EncoderBase):
         w = _fold_weight_norm(sd)                                          # [D, Cg, k]
         wp = torch.zeros((G, Cg, k, self.pos_kc), dtype=torch.float32)
         wp[:, :, :, :Cg] = w.view(G, Cg, Cg, k).permute(0, 1, 3, 2)
-        # the positional conv runs in the LAYER format: in "f16" mode it costs 3x less than on the fp32x stem and, unlike the conv
-        # stack and the projection, moves the error by nothing measurable (what-if on the CPU oracle: 7.08e-4 -> 7.12e-4)
-        self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"])
+        # The positional conv runs in the LAYER format when its dot products are short enough: in "f16" mode it then costs 3x
+        # less than on the fp32x stem and, unlike the conv stack and the projection, moves the error by nothing measurable
+        # (WavLM-large, K = 128 taps x 64 channels: 6.8e-4 either way; HuBERT-xlarge, 128 x 80: 8.0e-4 either way).  XLS-R-2B's
+        # 128 x 120 = 15 360-long sums do feel fp16 operands (7.0e-4 -> 8.3e-4 at full geometry), so they stay on the stem format.
+        self.pos_in_stem = self.mode_name == "f16" and Cg * k > 128 * 80
+        self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"], stem=self.pos_in_stem)
         self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
         self.layers = []
         for i in range(geo.num_layers):
@@ -585,7 +588,7 @@ class SpeechEncoder(_EncoderBase):
         ar["feat_f32"] = torch.empty((cap["M"], C0), dtype=torch.float32, device=dev)
         ar["feat_act"] = self._new_act(cap["M"], C0, stem=True)
         ar["proj_f32"] = torch.empty((cap["M"], D), dtype=torch.float32, device=dev)
-        ar["halo_act"] = self._new_act(cap["halo"], D, zero=True, extra_rows=1)
+        ar["halo_act"] = self._new_act(cap["halo"], D, zero=True, extra_rows=1, stem=self.pos_in_stem)
         ar["states"] = torch.empty((geo.num_layers + 1, cap["M"], D), dtype=torch.float32, device=dev)
         ar["first_groups"] = 2                               # ser_row_center writes one (sum, sum^2) slot + one zero slot
         self._layer_buffers(ar, cap["M"], ar["first_groups"])
@@ -784,14 +787,15 @@ class SpeechEncoder(_EncoderBase):
         # a9: feature projection (LN -> Linear); also scatter into the zero-halo'd pos-conv input
         self._layernorm(pl["feat_f32"], C0, self.proj_ln, M, C0, out_act=pl["feat_act"], stem=True)
         self._gemm(pl["feat_act"], self.proj, M, out_f32=pl["proj_f32"], ldo_f32=D,
-                   out_act=pl["halo_act"], out_rowmap=pl["halo_rowmap"], stem=True, out_mode=self.mode)
+                   out_act=pl["halo_act"], out_rowmap=pl["halo_rowmap"], stem=True,
+                   out_mode=self.stem_mode if self.pos_in_stem else self.mode)
         # a10: grouped positional conv + GELU + residual -> hidden_states[0]
         states = pl["states"]
         G, Cg, kc = geo.pos_conv_groups, self.pos_cg, self.pos_kc
         self._gemm(pl["halo_act"], self.pos, M, a_rowoff=pl["pos_rowoff"], kc=kc, ldj=D, groups=G,
                    a_group_stride=Cg, w_group_stride=Cg * geo.pos_conv_kernel * kc, c_group_stride=Cg,
                    N=Cg, K=geo.pos_conv_kernel * kc, act=_lib.ACT_GELU, residual=pl["proj_f32"], ldr=D,
-                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg)
+                   out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg, stem=self.pos_in_stem)
         # a11/a12: stable-LayerNorm encoder layers (LayerNorms deferred into the GEMMs)
         self._run_layers(pl, states, pl["first_groups"], B, pl["Tmax"])
 
@@ -1122,7 +1126,10 @@ class DebertaEncoder(_EncoderBase):
                  c2p_col=(c2p_row - lo).to(torch.int32).to(self.device), p2c_col=(p2c_row - lo).to(torch.int32).to(self.device), layers=[])
         for lay in self.layers:
             cut = lambda m: m[lo:lo + Nr].reshape(Nr, H, dh).permute(1, 0, 2).reshape(H * Nr, dh)     # noqa: E731
-            w["layers"].append((self._linear(cut(lay["pos_k"]), None), self._linear(cut(lay["pos_q"]), None)))
+            # ONE grouped GEMM gives both position terms: the k columns follow the q columns in the packed projection, so
+            # group g < H reads query head g and group H + h reads key head h with the same column step dh; the weights are
+            # the position keys of every head followed by the position queries of every head
+            w["layers"].append(self._linear(torch.cat([cut(lay["pos_k"]), cut(lay["pos_q"])], 0), None))
         self._windows[T] = w
         return w
 
@@ -1138,8 +1145,7 @@ class DebertaEncoder(_EncoderBase):
         pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
         pl["xa"], pl["ha"] = self._new_act(M, D), self._new_act(M, D)
         pl["qkv"], pl["ctx"], pl["ffn"] = self._new_act(M, 3 * D), self._new_act(M, D), self._new_act(M, Fd)
-        pl["c2p"] = torch.empty((M, geo.heads * win["Nr"]), dtype=torch.float32, device=dev)
-        pl["p2c"] = torch.empty((M, geo.heads * win["Nr"]), dtype=torch.float32, device=dev)
+        pl["posterms"] = torch.empty((M, 2 * geo.heads * win["Nr"]), dtype=torch.float32, device=dev)   # [c2p of every head | p2c of every head]
         pl["frame_offs"] = torch.tensor(pl["frame_offs_host"], dtype=torch.int32, device=dev)
         pl["bias2d"] = torch.zeros((B, geo.heads, T, (T + 63) // 64 * 64), dtype=torch.float32, device=dev)   # dense c2p + p2c bias
         pl["tmp"] = torch.empty((M, D), dtype=torch.float32, device=dev)
@@ -1181,16 +1187,15 @@ class DebertaEncoder(_EncoderBase):
         bias2d = pl["bias2d"]
         for i, lay in enumerate(self.layers):
             x = states[i]
-            pos_k, pos_q = win["layers"][i]
             self._gemm(xa, lay["qkv"], M, out_act=qkv, col_scale=s2, col_scale_end=D)
-            # content -> position and position -> content terms: one grouped GEMM each (group = head, K = dh)
-            self._gemm(qkv, pos_k, M, groups=H, a_group_stride=dh, w_group_stride=Nr * dh, c_group_stride=Nr, N=Nr, K=dh,
-                       out_f32=pl["c2p"], ldo_f32=H * Nr)
-            self._gemm(qkv, pos_q, M, groups=H, a_group_stride=dh, w_group_stride=Nr * dh, c_group_stride=Nr, N=Nr, K=dh,
-                       a_ptr_offset=2 * D, out_f32=pl["p2c"], ldo_f32=H * Nr)
+            # content -> position (q x position keys) and position -> content (k x position queries) terms: one grouped GEMM,
+            # group = (term, head), K = dh
+            pt = pl["posterms"]
+            self._gemm(qkv, win["layers"][i], M, groups=2 * H, a_group_stride=dh, w_group_stride=Nr * dh, c_group_stride=Nr,
+                       N=Nr, K=dh, out_f32=pt, ldo_f32=2 * H * Nr)
             # dense bias of every (sequence, head) from the two gathers, then the matrix-core attention kernel of the speech
             # encoders with it (the 80-token VALU kernel ser_deberta_attention was a third of the step)
-            check(lib.ser_deberta_bias(pl["c2p"].data_ptr(), pl["p2c"].data_ptr(), H * Nr, Nr, win["c2p_col"].data_ptr(),
+            check(lib.ser_deberta_bias(pt.data_ptr(), pt.data_ptr() + 4 * H * Nr, 2 * H * Nr, Nr, win["c2p_col"].data_ptr(),
                                        win["p2c_col"].data_ptr(), key_lens.data_ptr(), bias2d.data_ptr(), bias2d.shape[-1],
                                        B, T, H, float(s2), st), "ser_deberta_bias")
             self._attention(qkv, pl["frame_offs"], B, T, pl["ctx"], key_lens=key_lens, bias2d=bias2d)
