@@ -190,7 +190,7 @@ def end_to_end_leg(args, enc, geo, whisper, n_files, num_samples):
         sink = io.StringIO()
         with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(io.StringIO()):
             (driver.run_whisper if whisper else driver.run_speech)(argv, extractor_factory=factory)
-        last = getattr(driver._run, "last", None)
+        last = dict(driver.LAST_RUN) or None
         written = len(os.listdir(out)) if os.path.isdir(out) else 0
         if not last or written != n_files:
             return {"error": f"driver wrote {written} of {n_files} files", "log_tail": sink.getvalue()[-400:]}

@@ -210,6 +210,9 @@ class _Extractor:
         return buf[:rows]
 
 
+LAST_RUN: dict = {}       # counters of the most recent _run in this process (bench.py's end-to-end leg reads them)
+
+
 def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -> int:
     """``extractor_factory(args, whisper, device)`` replaces ``_Extractor`` (bench.py hands in its already-built encoder;
     the CPU gloo tests hand in a stub so that everything around the model call -- sharding, the compat layer index,
@@ -393,7 +396,8 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
         "utt_per_s": round(total_done / max(wall, 1e-9), 1), "audio_s_per_s": round(total_audio / max(wall, 1e-9), 1),
         "mode": args.mode, "ssl_type": args.ssl_type, "batch_size": args.batch_size, "num_workers": args.num_workers,
         "host_cpus": os.cpu_count()}))
-    _run.last = dict(done=int(total_done), wall_s=wall, audio_s=total_audio, launch_thread=dict(tm))
+    LAST_RUN.clear()
+    LAST_RUN.update(done=int(total_done), wall_s=wall, audio_s=total_audio, launch_thread=dict(tm))
     if args.timing:
         log("launch thread: " + ", ".join(f"{k} {v:.3f} s" for k, v in tm.items()) + f", total {dt:.3f} s")
         if getattr(ex, "tm", None):
