@@ -348,7 +348,7 @@ def main():
         trace, enc.gemm_trace = enc.gemm_trace, None
     # Attention-block leg (north_star target: >= 30 % of the bf16 MFMA peak on packed QKV projection -> attention ->
     # output projection): one more eager pass with one event pair per layer around exactly that sub-graph.
-    blocks = blocks_full = None
+    blocks = blocks_full = blocks_conc = None
     if not args.no_trace and not whisper and geo.family != C.FAMILY_ROBERTA:
         enc.block_trace = []
         for _ in range(args.steps):
@@ -361,6 +361,27 @@ def main():
             enc.forward(packed, lengths, slot=len(groups))
         torch.cuda.synchronize()
         blocks_full, enc.block_trace = enc.block_trace, None
+        # ... and the sub-graph alone the way the step runs it: both utterance groups' attention blocks at once, on two streams
+        blocks_conc = None
+        if len(groups) == 2:
+            main = torch.cuda.current_stream()
+            sides = [torch.cuda.Stream(device=device) for _ in groups]
+            pairs = []
+            for it in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for st_ in sides:
+                    st_.wait_stream(main)
+                for slot, (st_, (w, l)) in enumerate(zip(sides, groups)):
+                    with torch.cuda.stream(st_):
+                        n_calls = enc.attention_blocks_only(l, slot)
+                for st_ in sides:
+                    main.wait_stream(st_)
+                e1.record()
+                if it:
+                    pairs.append((e0, e1))
+            torch.cuda.synchronize()
+            blocks_conc = (sum(a.elapsed_time(b) for a, b in pairs) * 1e3 / len(pairs) / n_calls, args.batch)
 
     elapsed = D.max_over_ranks(elapsed)
 
@@ -437,6 +458,14 @@ def main():
                 out["attention_block"]["whole_batch_per_launch"] = {
                     "utterances_per_launch": blocks_full[0][2], "us_per_layer_call": round(us_f, 2),
                     "achieved": round(ach_f, 1), "frac": round(ach_f / MFMA_BF16_PEAK_TFLOPS, 4)}
+            if blocks_conc:
+                us_c, utts_c = blocks_conc
+                ach_c = gf_block * utts_c / us_c * 1e3
+                out["attention_block"]["two_concurrent_groups"] = {
+                    "utterances_per_layer_call": utts_c, "us_per_layer_call": round(us_c, 2), "achieved": round(ach_c, 1),
+                    "frac": round(ach_c / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "measured": "the sub-graph alone (no FFN between the blocks), both 8-utterance groups at once on two streams as "
+                                "the timed step runs them; HIP events around fork .. join of all layers"}
 
         # ---- parity_mode: throughput + measured errors of the mode that meets north_star's 1e-3 (rank 0, N = 1)
         checks_ok = verification is not None and verification["graph_replay_equals_eager_bitwise"] and verification["all_finite"]

@@ -391,6 +391,29 @@ class _EncoderBase:
             gx = gD
         self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
 
+    @_on_stream
+    def attention_blocks_only(self, lengths: Sequence[int], slot: int) -> int:
+        """Measurement aid (bench.py ``attention_block``): launch ONLY the attention sub-graph of every layer -- packed QKV(+gate)
+        projection -> attention -> output projection -- over the buffers the slot's last forward left behind (same shapes,
+        same kernels, stale but finite data), on the current stream.  Returns the number of layer calls."""
+        pl = self._plan(lengths, slot)
+        geo = self.geo
+        M, D, B = pl["M"], geo.hidden, len(lengths)
+        max_frames = pl.get("Tmax", geo.max_source_positions)
+        wavlm = geo.family == FAMILY_WAVLM
+        gD = self._stat_groups(D)
+        for i, lay in enumerate(self.layers):
+            self._gemm(pl["xa"], lay["qkv"], M, ln_stats=(pl["px0"] if i == 0 else pl["px"]), ln_groups=(pl["first_groups"] if i == 0 else gD),
+                       out_act=pl["qkv"], col_scale=geo.head_dim ** -0.5 * 1.4426950408889634, col_scale_end=D, ln_mean=(pl["sx"], pl["mx"]))
+            if wavlm:
+                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"], table_T=pl["Tmax"],
+                                gru_const=lay["gate_c"])
+            else:
+                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
+            self._gemm(pl["ctx"], lay["out"], M, residual=pl["h"], ldr=D, out_f32=pl["h"], ldo_f32=D, out_act=pl["ha"],
+                       stat_out=pl["ph"], stat_groups=gD, shift=(pl["mx"], pl["sh"], lay["out_bias_mean"]))
+        return len(self.layers)
+
     def _layer_weights(self, sd, p: str, a: str, ln1: str, ln2: str, fc1: str, fc2: str, k_bias: bool, gate: bool):
         """One encoder layer's GEMM operands; LN1 folds into the packed QKV (+gate) projection, LN2 into FC1."""
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
