@@ -142,8 +142,8 @@ def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
     assert torch.isfinite(loss)
 
 
-@pytest.mark.parametrize("family", ["wavlm", "hubert"])
-def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, capsys, family):
+@pytest.mark.parametrize("family,mode", [("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16")])
+def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, capsys, family, mode):
     """Next row 8f-4 end to end (preprocessing/preprocess_speech_pretrained.py:108-177): a PEFT-wrapped checkpoint --
     ``wavlm.base_model.model.*`` names, ``q_proj`` / ``v_proj`` split into ``base_layer`` + ``lora_A`` / ``lora_B`` (r = 8,
     alpha = 16), a classifier head beside the encoder -- goes through ``run_speech --checkpoint``; the HIP path sees
@@ -185,7 +185,7 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
     C._REGISTRY["tiny-lora-test"] = geo
     try:
         rc = driver.run_speech(["--ssl_type", "tiny-lora-test", "--wav_dir", str(wav_dir), "--save_path", str(out),
-                                "--checkpoint", str(ck), "--mode", "fp32x", "--n_layer", "-1", "--lora_alpha", "16"])
+                                "--checkpoint", str(ck), "--mode", mode, "--n_layer", "-1", "--lora_alpha", "16"])
     finally:
         C._REGISTRY.pop("tiny-lora-test")
     assert rc == 0, capsys.readouterr().out

@@ -328,3 +328,23 @@ def test_driver_save_format_npy_and_bad_layer_report(tmp_path, capsys):
     log = capsys.readouterr().out
     assert log.count("tuple index out of range") == 3 and os.listdir(out2) == []
     assert "SER_RUN " in log
+
+
+def test_driver_on_an_empty_directory(tmp_path, capsys):
+    """Nothing to do is not an error: the reference prints its header lines and exits 0 (preprocess_speech.py:87-124)."""
+    class Stub:
+        pipelined = False
+
+        def __init__(self, args, whisper, device):
+            self.geo = C.TINY_WAVLM
+            self.weight_source = "stub"
+
+        def extract(self, waves, layer_index):
+            raise AssertionError("no file, no model call")
+
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(tmp_path / "out")], whisper=False, extractor_factory=Stub) == 0
+    log = capsys.readouterr().out
+    assert "0 file are going to be processed..." in log and "0 utterances" in log
+    assert os.listdir(tmp_path / "out") == []
