@@ -201,4 +201,8 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
         worst = max(worst, float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))))
         changed = max(changed, float((plain - ref).abs().max()))
     assert changed > 0.1, changed            # the adapters matter ...
-    assert worst < 1e-3, worst               # ... and the merged HIP path equals the un-merged reference arithmetic
+    # ... and the merged HIP path equals the un-merged reference arithmetic.  fp32x: the parity gate.  f16: these adapters make
+    # the query projection ~4x larger than the base weights, i.e. attention logits ~4x larger, and single-product operand
+    # rounding (2^-12 relative per operand) moves a softmax weight by (logit error) * ln 2: measured 2.9e-3 here against
+    # 6-8e-4 on the unadapted geometries.  That envelope of the mode is stated in DESIGN.md section 4; fp32x stays the default.
+    assert worst < (1e-3 if mode == "fp32x" else 5e-3), worst
