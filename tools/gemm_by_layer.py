@@ -7,7 +7,8 @@ from interspeech_ser_amd.engine import build_encoder
 from interspeech_ser_amd.weights import synthetic_state_dict
 geo = C.geometry_for(sys.argv[1] if len(sys.argv) > 1 else "microsoft/wavlm-large")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-enc = build_encoder(geo, synthetic_state_dict(geo, 0), "cuda:0", "bf16")
+mode = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+enc = build_encoder(geo, synthetic_state_dict(geo, 0), "cuda:0", mode)
 rng = np.random.default_rng(1)
 waves = [(0.1 * rng.standard_normal(160000)).astype(np.float32) for _ in range(B)]
 lengths = [160000] * B
