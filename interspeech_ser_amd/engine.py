@@ -1041,6 +1041,11 @@ class TextEncoder(_EncoderBase):
         B, T = input_ids.shape
         if attention_mask.shape != input_ids.shape:
             raise ValueError("attention_mask must have the shape of input_ids")
+        if T + geo.pad_token_id + 1 > geo.max_positions:
+            # position ids run up to T + padding_idx (HF modeling_roberta.py:142): the table must hold them
+            raise ValueError(f"{T} tokens need {T + geo.pad_token_id + 1} position embeddings, the model has {geo.max_positions}")
+        if int(input_ids.min()) < 0 or int(input_ids.max()) >= geo.vocab_size:
+            raise ValueError("token id outside the vocabulary")
         mask = attention_mask.to(torch.int64).cpu()
         klen = mask.sum(dim=1)
         if not torch.equal(mask, (torch.arange(T)[None, :] < klen[:, None]).to(torch.int64)) or int(klen.min()) < 1:
@@ -1183,6 +1188,8 @@ class DebertaEncoder(_EncoderBase):
         B, T = input_ids.shape
         if attention_mask.shape != input_ids.shape:
             raise ValueError("attention_mask must have the shape of input_ids")
+        if int(input_ids.min()) < 0 or int(input_ids.max()) >= self.geo.vocab_size:
+            raise ValueError("token id outside the vocabulary")
         mask = attention_mask.to(torch.int64).cpu()
         klen = mask.sum(dim=1)
         if not torch.equal(mask, (torch.arange(T)[None, :] < klen[:, None]).to(torch.int64)) or int(klen.min()) < 1:
