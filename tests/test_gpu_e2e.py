@@ -482,3 +482,22 @@ def test_whisper_command_list_and_pipeline_equal_eager():
         assert len(g) == len(w)
         for x, y, wv in zip(g, w, waves):
             assert x.shape == y.shape == (whisper_saved_rows(len(wv), geo.hidden), geo.hidden) and torch.equal(x, y)
+
+
+def test_text_encoder_refuses_out_of_table_inputs():
+    """A sequence longer than the position table, or a token id outside the vocabulary, would index past the embedding
+    tables on the device: refused on the host (the drivers report it per batch like any other failure)."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import TextEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_ROBERTA                                          # 90 positions, 300 tokens
+    enc = TextEncoder(geo, synthetic_state_dict(geo, 2), "cuda:0", mode="bf16")
+    ok = torch.full((1, 80), 5, dtype=torch.int64)
+    enc.forward(ok, torch.ones_like(ok))
+    long = torch.full((1, 89), 5, dtype=torch.int64)
+    with pytest.raises(ValueError):
+        enc.forward(long, torch.ones_like(long))
+    bad = ok.clone()
+    bad[0, 3] = geo.vocab_size
+    with pytest.raises(ValueError):
+        enc.forward(bad, torch.ones_like(bad))
