@@ -348,3 +348,17 @@ def test_driver_on_an_empty_directory(tmp_path, capsys):
     log = capsys.readouterr().out
     assert "0 file are going to be processed..." in log and "0 utterances" in log
     assert os.listdir(tmp_path / "out") == []
+
+
+def test_native_wav_reader_extensible_header_and_extra_chunks(tmp_path):
+    """WAVE_FORMAT_EXTENSIBLE (format tag 0xFFFE, sub-format PCM) with a LIST chunk before ``fmt `` and an odd-sized chunk before
+    ``data`` -- what many recorders write and Python's ``wave`` module refuses: the native reader decodes it like plain PCM16."""
+    import struct
+    pcm = (np.random.default_rng(3).integers(-20000, 20000, size=777)).astype("<i2")
+    fmt = struct.pack("<HHIIHHHHIH14s", 0xFFFE, 1, 16000, 32000, 2, 16, 22, 16, 4, 1, b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71")
+    chunks = b"LIST" + struct.pack("<I", 4) + b"INFO" + b"fmt " + struct.pack("<I", len(fmt)) + fmt \
+        + b"junk" + struct.pack("<I", 3) + b"abc\x00" + b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes()
+    p = tmp_path / "ext.wav"
+    p.write_bytes(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
+    got = frontend.load_wav_16k(str(p))
+    assert got.dtype == np.float32 and np.array_equal(got, pcm.astype(np.float32) / 32768.0)
