@@ -236,6 +236,16 @@ int ser_pack_act(const float* x, int B, int C, int T, int halo, void* out, int64
 int ser_embed_ln_masked(const int32_t* ids, const float* word_emb, const float* ln_g, const float* ln_b, float eps,
                         const int32_t* key_lens, float* out_f32, void* out_act, int64_t out_plane_stride,
                         int mode, int B, int T, int D, void* stream);
+/* ConvLayer of deberta-v2-xlarge / xxlarge (HF modeling_deberta_v2.py ConvLayer; the checkpoint the reference's README runs
+ * preprocess_deroberta.py with, README.md:66): Conv1d(D, D, 3) over the token axis of the embedding output, activation, + layer
+ * 0's output, LayerNorm, padded rows zero.  The conv is ser_gemm's implicit-conv map over the halo'd copy ser_pack_rows makes
+ * (row b*(T+2*halo) + halo + t of `out` = split(x[b*T + t]); the halo rows are the caller's zeros); ser_zero_padded_rows zeroes
+ * rows t >= key_lens[b] of an fp32 matrix and / or its act copy. */
+int ser_pack_rows(const float* x, int64_t ldx, int B, int T, int D, int halo, void* out, int64_t ldo, int64_t out_plane_stride,
+                  int mode, void* stream);
+int ser_zero_padded_rows(float* x, int64_t ldx, void* act, int64_t lda, int64_t plane_stride, int mode, const int32_t* key_lens,
+                         int B, int T, int D, void* stream);
+
 /* Dense disentangled-attention bias for ser_attention's bias2d argument (the matrix-core path the DeBERTa encoder uses):
  *   out[b][h][q][k] = c2p[q][c2p_col[q-k]] + p2c_scale * p2c[k][p2c_col[k-q]]   for q, k < key_lens[b], else 0;   row pitch ld.
  * c2p is expected from a q that already carries the score scale (ser_gemm col_scale), p2c from the plain k. */

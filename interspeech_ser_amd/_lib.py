@@ -147,6 +147,8 @@ _SIGNATURES = {
                                     c_int, c_int, c_int, c_int, c_void_p]),
     "ser_deberta_attention": (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ser_pack_rows": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "ser_zero_padded_rows": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ser_deberta_bias": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int,
                                  c_float, c_void_p]),
     "ser_run": (c_int, [c_void_p, C.c_int32, c_void_p, c_void_p]),

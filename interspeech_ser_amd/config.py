@@ -53,6 +53,8 @@ class EncoderGeometry:
     type_vocab_size: int = 1
     # DeBERTa-v2/v3 disentangled attention (log-bucketed relative positions, shared q/k projections for positions)
     position_buckets: int = 256
+    # DeBERTa-v2 xlarge / xxlarge: ConvLayer after encoder layer 0 (HF modeling_deberta_v2.py ConvLayer; 0 = none, as in v3)
+    text_conv_kernel: int = 0
     name: str = ""
 
     @property
@@ -109,8 +111,21 @@ DEBERTA_V3_BASE = EncoderGeometry(
     family=FAMILY_DEBERTA, num_layers=12, hidden=768, heads=12, ffn=3072, vocab_size=128100, max_positions=512,
     pad_token_id=0, type_vocab_size=0, layer_norm_eps=1e-7, position_buckets=256, name="microsoft/deberta-v3-base")
 
+# deberta-v2-xlarge is what the reference's README runs preprocess_deroberta.py with (README.md:66): the v3 attention
+# settings plus conv_kernel_size = 3, conv_act = "gelu" (a token-axis Conv1d of the embeddings added to layer 0's output)
+DEBERTA_V2_XLARGE = EncoderGeometry(
+    family=FAMILY_DEBERTA, num_layers=24, hidden=1536, heads=24, ffn=6144, vocab_size=128100, max_positions=512,
+    pad_token_id=0, type_vocab_size=0, layer_norm_eps=1e-7, position_buckets=256, text_conv_kernel=3,
+    name="microsoft/deberta-v2-xlarge")
+DEBERTA_V2_XXLARGE = EncoderGeometry(
+    family=FAMILY_DEBERTA, num_layers=48, hidden=1536, heads=24, ffn=6144, vocab_size=128100, max_positions=512,
+    pad_token_id=0, type_vocab_size=0, layer_norm_eps=1e-7, position_buckets=256, text_conv_kernel=3,
+    name="microsoft/deberta-v2-xxlarge")
+
 _REGISTRY = {
     "microsoft/deberta-v3-large": DEBERTA_V3_LARGE,
+    "microsoft/deberta-v2-xlarge": DEBERTA_V2_XLARGE,
+    "microsoft/deberta-v2-xxlarge": DEBERTA_V2_XXLARGE,
     "microsoft/deberta-v3-base": DEBERTA_V3_BASE,
     "roberta-large": ROBERTA_LARGE,
     "FacebookAI/roberta-large": ROBERTA_LARGE,
@@ -124,7 +139,7 @@ _REGISTRY = {
 
 
 def tiny_geometry(family: str, *, hidden: int = 128, heads: int = 2, layers: int = 2,
-                  ffn: int = 256, conv_dim: int = 64, pos_groups: int = 2) -> EncoderGeometry:
+                  ffn: int = 256, conv_dim: int = 64, pos_groups: int = 2, text_conv_kernel: int = 0) -> EncoderGeometry:
     """Small geometries with the real kernel/stride tuples; used by the parity
     fixtures under tests/golden (SURVEY 8c item 1).  ``hidden // heads`` selects
     the head-dim code path (64 WavLM/Whisper, 80 HuBERT-XL, 120 XLS-R-2B) and
@@ -136,7 +151,8 @@ def tiny_geometry(family: str, *, hidden: int = 128, heads: int = 2, layers: int
         # 16 buckets: relative distances beyond +-8 are log-bucketed already at 80 tokens, like +-128 at 512 in v3-large
         return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads, ffn=ffn, vocab_size=300,
                                max_positions=512, pad_token_id=0, type_vocab_size=0, layer_norm_eps=1e-7,
-                               position_buckets=16, name=f"tiny-{family}-d{hidden}h{heads}")
+                               position_buckets=16, text_conv_kernel=text_conv_kernel,
+                               name=f"tiny-{family}-d{hidden}h{heads}" + ("-conv" if text_conv_kernel else ""))
     if family == FAMILY_WHISPER:
         return EncoderGeometry(family=family, num_layers=layers, hidden=hidden, heads=heads,
                                ffn=ffn, n_mels=128, max_source_positions=1500,
@@ -174,3 +190,4 @@ TINY_HUBERT = tiny_geometry(FAMILY_HUBERT, hidden=320, heads=4, ffn=384, pos_gro
 TINY_WHISPER = tiny_geometry(FAMILY_WHISPER, hidden=128, heads=2, ffn=256)
 TINY_ROBERTA = tiny_geometry(FAMILY_ROBERTA, hidden=128, heads=2, ffn=256)
 TINY_DEBERTA = tiny_geometry(FAMILY_DEBERTA, hidden=128, heads=2, ffn=256)
+TINY_DEBERTA_CONV = tiny_geometry(FAMILY_DEBERTA, hidden=128, heads=2, ffn=256, text_conv_kernel=3)      # deberta-v2-xlarge style

@@ -160,6 +160,70 @@ __global__ __launch_bounds__(128) void deberta_attention_kernel(
             store_act4<MODE>(orow + 4 * d4, out_plane, o[d4][0] * inv, o[d4][1] * inv, o[d4][2] * inv, o[d4][3] * inv);
 }
 
+// --------------------------------------------------------------------- ConvLayer support (deberta-v2 xlarge / xxlarge)
+// DebertaV2Encoder runs a token-axis Conv1d(D, D, 3) over the EMBEDDING output after encoder layer 0 (HF
+// modeling_deberta_v2.py ConvLayer).  The conv itself is ser_gemm's implicit-conv map over a zero-halo'd copy of the rows
+// (one zero row before and after every sequence), GELU and the residual ride in its epilogue, ser_layernorm follows; these two
+// row kernels provide the halo'd operand copy and the final "padded rows are zero" of that layer.
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ x, int64_t ldx, int T, int D, int halo,
+                                                        unsigned short* __restrict__ o, int64_t ldo, int64_t plane, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;                    // one thread per 4 columns
+    if (i >= total) return;
+    const int c4 = (int)(i % (D / 4)) * 4;
+    const int64_t row = i / (D / 4);
+    const int64_t b = row / T;
+    const int t = (int)(row - b * T);
+    const f32x4 v = *(const f32x4*)(x + row * ldx + c4);
+    store_act4<MODE>(o + (b * (T + 2 * halo) + halo + t) * ldo + c4, plane, v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int ser_pack_rows(const float* x, int64_t ldx, int B, int T, int D, int halo, void* out, int64_t ldo,
+                             int64_t out_plane_stride, int mode, void* stream) {
+    if (!x || !out || B <= 0 || T <= 0 || D <= 0 || (D % 4) || halo < 0 || (ldx % 4) || (ldo % 4))
+        return ser_fail(-1, "ser_pack_rows: bad arguments");
+    const int64_t total = (int64_t)B * T * (D / 4);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(pack_rows_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, ldx, T, D, halo,
+                           (unsigned short*)out, ldo, out_plane_stride, total);
+    else if (mode == SER_MODE_BF16)
+        hipLaunchKernelGGL(pack_rows_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx, T, D, halo,
+                           (unsigned short*)out, ldo, out_plane_stride, total);
+    else return ser_fail(-2, "ser_pack_rows: bad mode %d", mode);
+    return ser_check_launch("ser_pack_rows");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void zero_padded_rows_kernel(float* __restrict__ x, int64_t ldx, unsigned short* __restrict__ a,
+                                                               int64_t lda, int64_t plane, const int32_t* __restrict__ key_lens,
+                                                               int T, int D, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % (D / 4)) * 4;
+    const int64_t row = i / (D / 4);
+    const int64_t b = row / T;
+    if ((int)(row - b * T) < key_lens[b]) return;
+    if (x) *(f32x4*)(x + row * ldx + c4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a) store_act4<MODE>(a + row * lda + c4, plane, 0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int ser_zero_padded_rows(float* x, int64_t ldx, void* act, int64_t lda, int64_t plane_stride, int mode,
+                                    const int32_t* key_lens, int B, int T, int D, void* stream) {
+    if ((!x && !act) || !key_lens || B <= 0 || T <= 0 || D <= 0 || (D % 4) || (ldx % 4) || (lda % 4))
+        return ser_fail(-1, "ser_zero_padded_rows: bad arguments");
+    const int64_t total = (int64_t)B * T * (D / 4);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (mode == SER_MODE_FP32X)
+        hipLaunchKernelGGL(zero_padded_rows_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)act, lda, plane_stride, key_lens, T, D, total);
+    else if (mode == SER_MODE_BF16)
+        hipLaunchKernelGGL(zero_padded_rows_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)act, lda, plane_stride, key_lens, T, D, total);
+    else return ser_fail(-2, "ser_zero_padded_rows: bad mode %d", mode);
+    return ser_check_launch("ser_zero_padded_rows");
+}
+
 // ------------------------------------------------------------------------------------- dense bias
 // bias[b][h][q][k] = c2p[q][ci[q-k]] + p2c_scale * p2c[k][pi[k-q]]  for real tokens q, k < key_lens[b], else 0
 // (the attention kernel masks the keys a real query may not see and gives a padded query equal scores everywhere).

@@ -1133,6 +1133,14 @@ class DebertaEncoder(_EncoderBase):
                 fc1=self._linear(sd[p + ".intermediate.dense.weight"], sd[p + ".intermediate.dense.bias"]),
                 fc2=self._linear(sd[p + ".output.dense.weight"], sd[p + ".output.dense.bias"]),
                 ln2=self._ln_pair(sd, p + ".output.LayerNorm")))
+        # deberta-v2 xlarge / xxlarge: ConvLayer after layer 0 (HF modeling_deberta_v2.py ConvLayer) as an implicit-conv GEMM
+        self.text_conv = None
+        if geo.text_conv_kernel:
+            if geo.text_conv_kernel != 3:
+                raise ValueError("DeBERTa ConvLayer: kernel size 3 (deberta-v2-xlarge / xxlarge) is what is built")
+            wc = sd["encoder.conv.conv.weight"].float()                                    # [out, in, tap]
+            self.text_conv = dict(lin=self._linear(wc.permute(0, 2, 1).reshape(D, 3 * D), sd["encoder.conv.conv.bias"]),
+                                  ln=self._ln_pair(sd, "encoder.conv.LayerNorm"))
         self._windows: Dict[int, dict] = {}
 
     def _window(self, T: int):
@@ -1176,6 +1184,11 @@ class DebertaEncoder(_EncoderBase):
         pl["posterms"] = torch.empty((M, 2 * geo.heads * win["Nr"]), dtype=torch.float32, device=dev)   # [c2p of every head | p2c of every head]
         pl["frame_offs"] = torch.tensor(pl["frame_offs_host"], dtype=torch.int32, device=dev)
         pl["bias2d"] = torch.zeros((B, geo.heads, T, (T + 63) // 64 * 64), dtype=torch.float32, device=dev)   # dense c2p + p2c bias
+        if self.text_conv is not None:
+            pl["conv_in"] = self._new_act(B * (T + 2), D, zero=True)                       # [0][tokens of sequence b][0] per sequence
+            b_idx = np.repeat(np.arange(B, dtype=np.int64), T)
+            t_idx = np.tile(np.arange(T, dtype=np.int64), B)
+            pl["conv_rowoff"] = torch.tensor((b_idx * (T + 2) + t_idx) * D // 8, dtype=torch.int32, device=dev)   # tap 0 = token t-1
         pl["tmp"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         if len(self._cache) >= 4:
@@ -1234,6 +1247,16 @@ class DebertaEncoder(_EncoderBase):
             self._gemm(pl["ha"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
             self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=pl["tmp"], ldo_f32=D)
             self._layernorm(pl["tmp"], D, lay["ln2"], M, D, out_f32=states[i + 1], out_act=xa)
+            if i == 0 and self.text_conv is not None:
+                # ConvLayer: LN(layer-0 output + gelu(Conv1d_k3(embeddings))) with padded rows zero.  (HF zeroes the padded
+                # rows of the conv output before the activation too; gelu(0) = 0 and those rows are zeroed at the end anyway.)
+                ci = pl["conv_in"]
+                check(lib.ser_pack_rows(states[0].data_ptr(), D, B, T, D, 1, ci.ptr, D, ci.plane_stride, self.mode, st), "ser_pack_rows")
+                self._gemm(ci, self.text_conv["lin"], M, a_rowoff=pl["conv_rowoff"], kc=D, ldj=D, K=3 * D, act=_lib.ACT_GELU,
+                           residual=states[1], ldr=D, out_f32=pl["tmp"], ldo_f32=D)
+                self._layernorm(pl["tmp"], D, self.text_conv["ln"], M, D, out_f32=states[1], out_act=xa)
+                check(lib.ser_zero_padded_rows(states[1].data_ptr(), D, xa.ptr, D, xa.plane_stride, self.mode, key_lens.data_ptr(),
+                                               B, T, D, st), "ser_zero_padded_rows")
         return HiddenStates(states, pl["frame_offs_host"])
 
 

@@ -83,6 +83,11 @@ def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
         _layer_norm(sd, r, "embeddings.LayerNorm", D)
         sd["encoder.rel_embeddings.weight"] = r.normal(2 * geo.position_buckets, D, std=0.4)
         _layer_norm(sd, r, "encoder.LayerNorm", D)
+        if geo.text_conv_kernel:           # DebertaV2Encoder.conv (ConvLayer): Conv1d(D, D, k) over tokens + its LayerNorm
+            k = geo.text_conv_kernel
+            sd["encoder.conv.conv.weight"] = r.normal(D, D, k, std=0.7 / math.sqrt(D * k))
+            sd["encoder.conv.conv.bias"] = r.normal(D, std=0.05)
+            _layer_norm(sd, r, "encoder.conv.LayerNorm", D)
         for i in range(geo.num_layers):
             p = f"encoder.layer.{i}"
             _linear(sd, r, p + ".attention.self.query_proj", D, D, gain=1.6)

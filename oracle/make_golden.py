@@ -187,6 +187,7 @@ def roberta_case(tag, geo, seed):
 
 
 def deberta_case(tag, geo, seed):
+    """(with geo.text_conv_kernel: the deberta-v2-xlarge variant, ConvLayer after encoder layer 0)"""
     """DeBERTa-v3-style fixture (HIP counterpart: engine.DebertaEncoder, tests/test_gpu_e2e.py::test_deberta_golden)."""
     import transformers as tf
     sd = synthetic_state_dict(geo, seed)
@@ -196,7 +197,8 @@ def deberta_case(tag, geo, seed):
                              pad_token_id=geo.pad_token_id, relative_attention=True, position_buckets=geo.position_buckets,
                              norm_rel_ebd="layer_norm", share_att_key=True, pos_att_type=["p2c", "c2p"],
                              position_biased_input=False, max_relative_positions=-1,
-                             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+                             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                             **({"conv_kernel_size": geo.text_conv_kernel, "conv_act": "gelu"} if geo.text_conv_kernel else {}))
     model = tf.DebertaV2Model(cfg).eval()
     load_into(model, sd)
     max_len = 80
@@ -287,6 +289,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "deberta":
         deberta_case("tiny_deberta_d128h2", C.TINY_DEBERTA, 17)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "deberta_conv":
+        deberta_case("tiny_deberta_conv_d128h2", C.TINY_DEBERTA_CONV, 19)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stress":        # outlier-stress fixtures only
         stress_cases()
         return
@@ -301,6 +306,7 @@ def main():
     whisper_case("tiny_whisper_d128h2", C.TINY_WHISPER, 14, [16000, 100000])
     roberta_case("tiny_roberta_d128h2", C.TINY_ROBERTA, 15)
     deberta_case("tiny_deberta_d128h2", C.TINY_DEBERTA, 17)
+    deberta_case("tiny_deberta_conv_d128h2", C.TINY_DEBERTA_CONV, 19)
     stress_cases()
     full_size_pins()
 

@@ -400,6 +400,16 @@ def deberta_hidden_states(geo, sd: StateDict, input_ids: Tensor, attention_mask:
         f = F.linear(F.gelu(F.linear(h, sd[p + ".intermediate.dense.weight"], sd[p + ".intermediate.dense.bias"])),
                      sd[p + ".output.dense.weight"], sd[p + ".output.dense.bias"])
         h = _ln(h + f, sd, p + ".output.LayerNorm", eps)
+        if i == 0 and getattr(geo, "text_conv_kernel", 0):
+            # DebertaV2Encoder: after layer 0, ConvLayer(embeddings, layer-0 output, mask) (HF modeling_deberta_v2.py ConvLayer;
+            # deberta-v2-xlarge / xxlarge: conv_kernel_size 3, conv_act "gelu" -- the checkpoint the reference's README names for
+            # preprocess_deroberta.py, README.md:66): Conv1d over the token axis of the EMBEDDING output, padded rows zeroed,
+            # activation, + residual, LayerNorm, padded rows zeroed again.
+            kk = geo.text_conv_kernel
+            c = F.conv1d(states[0].transpose(0, 1)[None], sd["encoder.conv.conv.weight"], sd["encoder.conv.conv.bias"],
+                         padding=(kk - 1) // 2)[0].transpose(0, 1)
+            c = F.gelu(c * m[:, None])
+            h = _ln(h + c, sd, "encoder.conv.LayerNorm", eps) * m[:, None]
         states.append(h)
     return states
 

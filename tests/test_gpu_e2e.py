@@ -205,15 +205,16 @@ def test_roberta_golden(golden_dir, mode):
     assert worst < TOL[mode], worst
 
 
+@pytest.mark.parametrize("tag", ["tiny_deberta_d128h2", "tiny_deberta_conv_d128h2"])
 @pytest.mark.parametrize("mode", ["fp32x", "bf16"])
-def test_deberta_golden(golden_dir, mode):
+def test_deberta_golden(golden_dir, mode, tag):
     """DeBERTa-v3 variant of the text side: disentangled attention (log-bucketed relative positions live at 80 tokens with
     16 buckets), both-token mask, padded query rows, vs the HF DebertaV2Model fixture; plus batch-of-one == batched."""
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import build_encoder
     from interspeech_ser_amd.weights import synthetic_state_dict, state_dict_digest
-    geo = C.TINY_DEBERTA
-    gold = np.load(os.path.join(golden_dir, "tiny_deberta_d128h2.npz"))
+    geo = C.TINY_DEBERTA_CONV if "conv" in tag else C.TINY_DEBERTA      # conv: the deberta-v2-xlarge configuration (ConvLayer)
+    gold = np.load(os.path.join(golden_dir, tag + ".npz"))
     sd = synthetic_state_dict(geo, int(gold["seed"]))
     assert state_dict_digest(sd) == str(gold["digest"])
     ids = torch.from_numpy(np.stack([gold[f"ids_{j}"] for j in range(3)]))
@@ -230,7 +231,7 @@ def test_deberta_golden(golden_dir, mode):
         batched.append(hs.utterance(j, geo.num_layers).cpu().clone())
         for layer in range(ref.shape[0]):
             worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
-    print(f"deberta {mode}: worst rel err {worst:.3e}")
+    print(f"{tag} {mode}: worst rel err {worst:.3e}")
     assert worst < TOL[mode], worst
     one = enc.forward(ids[1:2], mask[1:2])
     torch.cuda.synchronize()

@@ -39,6 +39,15 @@ def test_geometry_registry():
         C.geometry_for("no/such-model")
 
 
+def test_deberta_v2_xlarge_geometry_is_registered():
+    """The checkpoint the reference's README names for preprocess_deroberta.py (README.md:66): 24 x 1536, 24 heads of 64,
+    ConvLayer with kernel 3; 884.6 M parameters with HF's DebertaV2Model at these values."""
+    g = C.geometry_for("microsoft/deberta-v2-xlarge")
+    assert (g.family, g.num_layers, g.hidden, g.heads, g.head_dim, g.ffn, g.text_conv_kernel) == (C.FAMILY_DEBERTA, 24, 1536, 24, 64, 6144, 3)
+    assert C.geometry_for("microsoft/deberta-v2-xxlarge").num_layers == 48
+    assert C.geometry_for("microsoft/deberta-v3-large").text_conv_kernel == 0
+
+
 def test_frame_arithmetic():
     g = C.WAVLM_LARGE
     assert g.frame_chain(160000) == [31999, 15999, 7999, 3999, 1999, 999, 499]
