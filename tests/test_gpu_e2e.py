@@ -275,9 +275,11 @@ def test_roberta_driver_files(tmp_path, capsys):
     assert rel_err(got, ref) < 1e-3
 
 
-def test_deberta_driver_files(tmp_path, capsys):
+@pytest.mark.parametrize("model", ["microsoft/deberta-v3-large", "microsoft/deberta-v2-xlarge"])
+def test_deberta_driver_files(tmp_path, capsys, model):
     """preprocess_deroberta.py counterpart end to end at the full deberta-v3-large geometry (160 reachable relative rows
-    at 80 tokens), stand-in tokenizer, against the oracle."""
+    at 80 tokens) and at deberta-v2-xlarge's (the checkpoint the reference's README names, README.md:66: 1536 wide, 24 heads,
+    ConvLayer after layer 0), stand-in tokenizer, against the oracle."""
     import pandas as pd
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd import driver
@@ -299,13 +301,13 @@ def test_deberta_driver_files(tmp_path, capsys):
         return ids, mask
 
     out = tmp_path / "feats"
-    rc = driver.run_deberta(["--roberta_type", "microsoft/deberta-v3-large", "--df_path", str(csv), "--save_path", str(out),
+    rc = driver.run_deberta(["--roberta_type", model, "--df_path", str(csv), "--save_path", str(out),
                              "--synthetic_weights", "--max_len", "80"], tokenize=fake_tokenize)
     assert rc == 0, capsys.readouterr().out
     assert sorted(os.listdir(out)) == ["a_0001.pt", "b_0002.pt"]
     got = torch.load(out / "b_0002.pt")
-    assert tuple(got.shape) == (80, 1024) and got.dtype == torch.float32
-    geo = C.DEBERTA_V3_LARGE
+    geo = C.geometry_for(model)
+    assert tuple(got.shape) == (80, geo.hidden) and got.dtype == torch.float32
     sd = synthetic_state_dict(geo, 7)
     ids, mask = fake_tokenize(["a much longer sentence with several more words in it"])
     with torch.no_grad():
