@@ -206,3 +206,64 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
     # rounding (2^-12 relative per operand) moves a softmax weight by (logit error) * ln 2: measured 2.9e-3 here against
     # 6-8e-4 on the unadapted geometries.  That envelope of the mode is stated in DESIGN.md section 4; fp32x stays the default.
     assert worst < (1e-3 if mode == "fp32x" else 5e-3), worst
+
+
+def test_whisper_lora_checkpoint_through_the_driver(tmp_path, capsys):
+    """preprocessing/preprocess_whisper_pretrained.py:115-190: a PEFT-wrapped Whisper (``whisper.base_model.model.*``, adapters on
+    q_proj / v_proj of encoder AND decoder, a classifier head) saved with torch.save as a ``.pt`` state dict, extracted with the
+    encoder only.  The HIP path merges the encoder's adapters at load; the oracle applies them un-merged."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.frontend import load_wav_16k, whisper_saved_rows
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.TINY_WHISPER
+    base = synthetic_state_dict(geo, 51)
+    g = torch.Generator().manual_seed(52)
+    r, alpha, D = 8, 16.0, geo.hidden
+    ckpt, ref_sd = {}, dict(base)
+    ref_sd["lora_scale"] = torch.tensor(alpha / r)
+    for k, v in base.items():
+        mod, _, leaf = k.rpartition(".")
+        if mod.endswith((".q_proj", ".v_proj")):
+            ckpt[f"whisper.base_model.model.{mod}.base_layer.{leaf}"] = v
+            if leaf == "weight":
+                A, B = torch.randn(r, D, generator=g) * 0.2, torch.randn(D, r, generator=g) * 0.2
+                ckpt[f"whisper.base_model.model.{mod}.lora_A.default.weight"] = A
+                ckpt[f"whisper.base_model.model.{mod}.lora_B.default.weight"] = B
+                ref_sd[mod + ".lora_A.weight"], ref_sd[mod + ".lora_B.weight"] = A, B
+        else:
+            ckpt["whisper.base_model.model." + k] = v
+    # what else such a checkpoint carries: an adapted decoder layer and the fine-tuning head
+    dq = "whisper.base_model.model.decoder.layers.0.self_attn.q_proj"
+    ckpt[dq + ".base_layer.weight"], ckpt[dq + ".base_layer.bias"] = torch.zeros(D, D), torch.zeros(D)
+    ckpt[dq + ".lora_A.default.weight"], ckpt[dq + ".lora_B.default.weight"] = torch.zeros(r, D), torch.zeros(D, r)
+    ckpt["classifier.0.weight"], ckpt["classifier.0.bias"] = torch.zeros(512, D), torch.zeros(512)
+    ck = tmp_path / "whisper_lora_ser.pt"
+    torch.save(ckpt, str(ck))
+    wav_dir, out = tmp_path / "wav", tmp_path / "pt"
+    wav_dir.mkdir()
+    waves = {"a.wav": synth(71, 16000), "b.wav": synth(72, 40000)}
+    for n, w in waves.items():
+        write_wav(wav_dir / n, w)
+    C._REGISTRY["tiny-whisper-lora-test"] = geo
+    try:
+        rc = driver.run_whisper(["--ssl_type", "tiny-whisper-lora-test", "--wav_dir", str(wav_dir), "--save_path", str(out),
+                                 "--checkpoint", str(ck), "--mode", "fp32x", "--n_layer", "-1"])
+    finally:
+        C._REGISTRY.pop("tiny-whisper-lora-test")
+    assert rc == 0, capsys.readouterr().out
+    worst = changed = 0.0
+    for n in waves:
+        x = load_wav_16k(str(wav_dir / n))
+        mel = torch.from_numpy(O.whisper_log_mel(x, geo.n_mels))
+        with torch.no_grad():
+            ref = O.whisper_hidden_states(geo, ref_sd, mel)[-1]
+            plain = O.whisper_hidden_states(geo, base, mel)[-1]
+        rows = whisper_saved_rows(len(x), geo.hidden)
+        got = torch.load(out / n.replace(".wav", ".pt"))
+        assert got.shape == (rows, geo.hidden)
+        worst = max(worst, float((got - ref[:rows]).abs().max() / max(1.0, float(ref.abs().max()))))
+        changed = max(changed, float((plain - ref).abs().max()))
+    assert changed > 0.05, changed
+    assert worst < 1e-3, worst
