@@ -24,6 +24,9 @@
 //   * blockIdx.x -> tile through a bijective XCD swizzle so each of the 8 L2s sees a contiguous run
 //     of tiles that share activation panels.
 #include "ser_common.h"
+#ifndef SER_GEMM_PP
+#define SER_GEMM_PP 3        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
+#endif
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -217,8 +220,67 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         __syncthreads();
     }
 
+    // Ping-pong schedule of the 8-wave tiles (two waves per SIMD: wave w and w + 4).  Left alone, both waves of a SIMD leave
+    // the per-tile barrier together, read their fragments together and then compete for the matrix pipe together.  Here
+    // waves 4..7 run ONE PHASE behind waves 0..3: a phase is either a batch of LDS reads (the fragments of one k-step for
+    // the 128x64 / 64x128 wave tiles, of the whole K tile for 64x64 ones, plus this wave's share of the next DMA) or the 32
+    // MFMAs that consume them; every phase ends in a barrier, so while one wave of a SIMD owns the matrix pipe the other one
+    // owns the LDS port.  With PH read phases per K tile, the early half reads batch (kt, s) in global phase 2 (PH kt + s) and
+    // multiplies in the next one; the late half does the same one phase later.  The stage of tile kt - 1 is last read in
+    // phase 2 PH kt - 1 (late half), so both halves may refill it from their first read phase of tile kt on, and both make
+    // sure tile kt + 1 has landed at the end of phase 2 PH (kt + 1) - 1, before the early half reads it.  Barrier counts match:
+    // the late half has one extra up front and skips the one after its last MFMA phase -- which overlaps the early half's
+    // epilogue.  Same arithmetic, same accumulation order: results are bit-identical to the plain ring.
+    constexpr int PP_BIT = LNEPI ? 4 : (TM * TN >= 32 ? 1 : 2);
+    constexpr bool PP = (SER_GEMM_PP & PP_BIT) && NW == 8 && NPL == 1 && KS == 2;
+    constexpr int PH = (TM * TN >= 32) ? KS : 1;                      // read phases per K tile
+    constexpr int SPP = KS / PH;                                      // k-steps per phase
+    if constexpr (PP) {
+        const int late = wave >> 2;
+        if (total >= ST - 1) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>();    // fewer tiles in flight when K is short
+        __builtin_amdgcn_s_barrier();                                 // tile 0 is visible to every wave
+        __builtin_amdgcn_sched_barrier(0);
+        if (late) __builtin_amdgcn_s_barrier();
+        int stage = 0;
+        for (int kt = 0; kt < total; ++kt) {
+            const bool more = kt + ST - 1 < total;
+            if (more) issue();
+            const char* sb = lds + stage * STAGE;
+            stage = (stage + 1 == ST) ? 0 : stage + 1;
+            const bool last = kt + 1 == total;
+#pragma unroll
+            for (int ph = 0; ph < PH; ++ph) {
+                bf16x8 af[SPP][TM], wf[SPP][TN];
+#pragma unroll
+                for (int u = 0; u < SPP; ++u) {
+#pragma unroll
+                    for (int x = 0; x < TM; ++x) af[u][x] = *(const bf16x8*)(sb + offA[ph * SPP + u] + x * 16 * ROWB);
+#pragma unroll
+                    for (int x = 0; x < TN; ++x) wf[u][x] = *(const bf16x8*)(sb + offW[ph * SPP + u] + x * 16 * ROWB);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ph == PH - 1 && late) { if (more) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int u = 0; u < SPP; ++u)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi)
+                            acc[ni][mi] = mfma16<MODE>(wf[u][ni], af[u][mi], acc[ni][mi]);
+                __builtin_amdgcn_s_setprio(0);
+                if (ph == PH - 1 && !late) { if (more) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ph == PH - 1 && last && late)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
     int c_stage = 0;
-    for (int kt = 0; kt < total; ++kt) {
+    for (int kt = 0; kt < (PP ? 0 : total); ++kt) {
         // tile kt has landed once at most (ST-2) younger tiles are still in flight
         if (kt + (ST - 2) < total) wait_vmcnt<LPT * (ST - 2)>();
         else wait_vmcnt<0>();
