@@ -53,8 +53,22 @@ struct AttnParams {
     const float* bias2d;
     int64_t b2d_ld;
     int b2d_T;            // rows per (utterance, head) block of bias2d (= max_frames: uniform-length batches)
+#ifdef SER_ATTN_DBG
+    unsigned long long* dbg;   // phase timestamps of one wave (tools/attn_phases.py; never in the product build)
+#endif
 };
+#ifdef SER_ATTN_DBG
+extern "C" { void* ser_attn_dbg_ptr = nullptr; }
+#define DBG_P(i) do { __builtin_amdgcn_sched_barrier(0); dbg_p[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DBG_T(i) do { __builtin_amdgcn_sched_barrier(0); if (dbg_on) dbg_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DBG_T(i) do {} while (0)
+#define DBG_P(i) do {} while (0)
+#endif
 
+#ifdef SER_ATTN_DBG
+__constant__ int ser_attn_dbg_block_dev = 100;
+#endif
 template <int DHP>
 __device__ __forceinline__ int k_swz(int key, int chunk) {
     return DHP == 64 ? (chunk ^ ((key >> 1) & 7)) : (chunk ^ (key & 15));
@@ -91,6 +105,11 @@ void attention_kernel(const AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SER_ATTN_DBG
+    const unsigned long long dbg_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long dbg_entry_rt = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dbg_p[6] = {0, 0, 0, 0, 0, 0};
+#endif
     // XCD-aware decode of the linear block id L: the q-tiles of one (utterance, head) sit at
     // L, L+8, L+16, ... -> same XCD (blocks are dealt round-robin over the 8 XCDs), close in time,
     // so K/V are fetched from HBM once and re-read from that XCD's L2 by the other q-tiles.
@@ -102,6 +121,7 @@ void attention_kernel(const AttnParams p) {
     const int T = p.frame_offs[b + 1] - row0;
     const int q0 = qt * (32 * NWV);
     if (q0 >= T) return;
+    DBG_P(0);
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
     const int TK = p.key_lens ? p.key_lens[b] : T;               // attendable keys (== T for speech)
@@ -169,7 +189,36 @@ void attention_kernel(const AttnParams p) {
     // tiles without key padding; with a dense bias every tile takes the per-element key check (real queries stop at TK,
     // padded ones at T; 80-token problems: two tiles)
     const int nfull = B2D ? 0 : ((TK & (ABKV - 1)) ? nkt - 1 : nkt);
+
+    // ---- this head's bias window, requested FIRST: vector-memory data returns in issue order, so these 8 words land before
+    // the K/V/Q data and the four shifted LDS copies are written while tile 0 is still in flight (they used to be requested
+    // last and copied, 20 guarded ds_write_b32 per thread, after everything had landed: 1.7 us of a 16 us block at T = 499).
+    // Thread i owns the aligned quad j = 4i..4i+3 of every copy: copy c [j] = window[j + c], so it needs window[4i .. 4i+6].
+    const float* trow = nullptr;
+    int bn = 0;
+    float bw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto bias_load = [&](int j4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = j4 + e;                                  // window index; jmin may be -3..-1, the tail runs past 2T-1
+            bw[e] = (e < 7 && idx < bn && idx + jmin >= 0 && j4 < p.bias_stride) ? trow[idx] : 0.f;
+        }
+    };
+    auto bias_write = [&](int j4) {
+        if (j4 < p.bias_stride) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *(f32x4*)(ldsB + c * p.bias_stride + j4) = (f32x4){bw[c], bw[c + 1], bw[c + 2], bw[c + 3]};
+        }
+    };
+    if (TBL) {
+        // only the distances this block's queries can see: key - query + T-1 in [jmin, jmin + 32*NWV + T + 63]
+        trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T) + jmin;
+        bn = 2 * T - 1 - jmin;
+        bias_load(4 * tid);
+    }
     stage_load(0, padded || nfull == 0);
+    DBG_P(1);
 
     // ---- Q fragments: lane holds Q[q][16*ks + 8*hh + j].  Requested here, with the gate inputs, so that their
     // latency overlaps the first K/V tile's and the bias row's instead of following them.
@@ -201,32 +250,17 @@ void attention_kernel(const AttnParams p) {
         }
     }
 
-    // ---- this head's bias row, 4 shifted copies: copy c [j] = table[h][(table_T-T) + j + c] -------
+    DBG_P(2);
+    // ---- this head's bias row, 4 shifted copies: copy c [j] = table[h][(table_T-T) + jmin + j + c] -------
     if (TBL) {
-        // each table element is read ONCE (5 independent loads in flight per thread and pass) and
-        // scattered into the 4 shifted copies; indices past 2T-1 are written as zeros (tail padding)
-        // only the distances this block's queries can see: key - query + T-1 in [jmin, jmin + 32*NWV + T + 63]
-        const float* trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T) + jmin;     // jmin may be -3..-1: guarded below
-        const int n = 2 * T - 1 - jmin, span = p.bias_stride + 3;
-        for (int base = 0; base < span; base += 5 * NT) {
-            float v[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int idx = base + u * NT + tid;
-                v[u] = (idx < n && idx + jmin >= 0) ? trow[idx] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int idx = base + u * NT + tid;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int j = idx - c;
-                    if (j >= 0 && j < p.bias_stride) ldsB[c * p.bias_stride + j] = v[u];
-                }
-            }
+        bias_write(4 * tid);
+        for (int j4 = 4 * (tid + NT); j4 < p.bias_stride; j4 += 4 * NT) {   // utterances beyond ~8 s: further passes
+            bias_load(j4);
+            bias_write(j4);
         }
     }
 
+    DBG_P(3);
     const int klim = (B2D && q >= TK) ? T : TK;                   // keys this lane's query may attend to
     const float* brow = B2D ? p.bias2d + ((int64_t)bh * p.b2d_T + qc) * p.b2d_ld : nullptr;
     const float c1 = p.scale * LOG2E;
@@ -249,9 +283,18 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
+#ifdef SER_ATTN_DBG
+    const bool dbg_on = p.dbg && (int)blockIdx.x == ser_attn_dbg_block_dev;
+    if (dbg_on && lane == 0) p.dbg[(wave * 64 + 63) * 6] = __builtin_amdgcn_s_memtime();     // end of the prologue loads' issue
+#endif
 
     stage_write(0);
+    DBG_P(4);
     __syncthreads();
+    DBG_P(5);
+#ifdef SER_ATTN_DBG
+    if (dbg_on && lane == 0) for (int i = 0; i < 6; ++i) p.dbg[(wave * 64 + 61) * 6 + i] = dbg_p[i] - dbg_entry;
+#endif
 
     auto tile = [&](int kt, auto ragged_tag) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
@@ -262,6 +305,10 @@ void attention_kernel(const AttnParams p) {
         const int cur = DB ? (kt & 1) : 0;
         const char* ldsK = smem + cur * BUF;
         const char* ldsV = ldsK + NP * TILE;
+#ifdef SER_ATTN_DBG
+        unsigned long long dbg_t[6] = {0, 0, 0, 0, 0, 0};
+#endif
+        DBG_T(0);
         if (DB && kt + 1 < nkt) stage_load(kt + 1, padded || kt + 1 >= nfull);   // issue early: lands under the MFMAs below
 
         // ---- S^T = K Q^T  (rows = keys in registers, col = query on the lane)
@@ -341,6 +388,7 @@ void attention_kernel(const AttnParams p) {
             }
         }
 
+        DBG_T(1);
         // transposed V reads: lane (qq,pp) of its 16-lane group addresses key kb+qq, 8 bytes at pp
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const int vg = lane >> 4, vqq = (lane >> 2) & 3, vpp = lane & 3;
@@ -386,6 +434,7 @@ void attention_kernel(const AttnParams p) {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
             mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
+        DBG_T(2);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
@@ -441,11 +490,13 @@ void attention_kernel(const AttnParams p) {
             lsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         }
         l_run = l_run * alpha + lsum;
+        DBG_T(3);
 
         // ---- publish the next tile
         if (kt + 1 < nkt) {
             if (DB) {
                 stage_write(cur ^ 1);                                // write late: other buffer, nobody reads it now
+                DBG_T(4);
                 __syncthreads();
             } else {
                 __syncthreads();                                     // everyone done with the single buffer
@@ -454,6 +505,11 @@ void attention_kernel(const AttnParams p) {
                 __syncthreads();
             }
         }
+        DBG_T(5);
+#ifdef SER_ATTN_DBG
+        if (dbg_on && lane == 0)
+            for (int i = 0; i < 6; ++i) p.dbg[(wave * 64 + kt) * 6 + i] = dbg_t[i];
+#endif
     };
     // the key-padding select exists only in the last tile of a ragged utterance
     if constexpr (B2D) {
@@ -463,6 +519,10 @@ void attention_kernel(const AttnParams p) {
         if (nfull < nkt) tile(nkt - 1, std::true_type{});
     }
 
+#ifdef SER_ATTN_DBG
+    if (dbg_on && lane == 0) { p.dbg[(wave * 64 + 62) * 6] = dbg_entry; p.dbg[(wave * 64 + 62) * 6 + 1] = __builtin_amdgcn_s_memtime();
+                               p.dbg[(wave * 64 + 62) * 6 + 2] = __builtin_amdgcn_s_memrealtime() - dbg_entry_rt; }
+#endif
     // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane owns query q, 4 consecutive d per register quad
     if (q < T) {
         const float inv = 1.0f / l_run;
@@ -538,6 +598,9 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
     p.bias2d = bias2d; p.b2d_ld = bias2d_ld; p.b2d_T = max_frames;
+#ifdef SER_ATTN_DBG
+    p.dbg = (unsigned long long*)ser_attn_dbg_ptr;
+#endif
     p.B = B; p.nq = (max_frames + 32 * nwv - 1) / (32 * nwv);
     dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * p.nq), 1, 1);
     hipStream_t s = (hipStream_t)stream;
