@@ -29,6 +29,11 @@
 #endif
 #include <stdlib.h>
 #include <stdio.h>
+#ifdef SER_GEMM_DBG
+// diagnostic build only (tools/gemm_clock.py): wave 0 of every block stamps s_memtime / s_memrealtime around its K loop
+extern "C" { void* ser_gemm_dbg_ptr = nullptr; }
+__device__ unsigned long long* ser_gemm_dbg_dev = nullptr;
+#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -231,6 +236,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     // sure tile kt + 1 has landed at the end of phase 2 PH (kt + 1) - 1, before the early half reads it.  Barrier counts match:
     // the late half has one extra up front and skips the one after its last MFMA phase -- which overlaps the early half's
     // epilogue.  Same arithmetic, same accumulation order: results are bit-identical to the plain ring.
+#ifdef SER_GEMM_DBG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int PP_BIT = LNEPI ? 4 : (TM * TN >= 32 ? 1 : 2);
     constexpr bool PP = (SER_GEMM_PP & PP_BIT) && NW == 8 && NPL == 1 && KS == 2;
     constexpr int PH = (TM * TN >= 32) ? KS : 1;                      // read phases per K tile
@@ -348,6 +356,16 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         }
     }
 
+#ifdef SER_GEMM_DBG
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = ser_gemm_dbg_dev;
+        if (d && wave == 0 && lane == 0 && blockIdx.y == 0) {
+            d[blockIdx.x * 2] = t1 - dbg_t0; d[blockIdx.x * 2 + 1] = r1 - dbg_r0;
+        }
+    }
+#endif
     // ---- epilogue: lane owns row m (per mi) and TN*4 consecutive columns ----------------------
     if constexpr (LNEPI) {
         // LayerNorm over the full row (N <= BN, one N tile) + GELU, two-pass statistics.
@@ -657,6 +675,15 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
     if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
     hipStream_t s = (hipStream_t)stream;
+#ifdef SER_GEMM_DBG
+    {
+        static void* planted = nullptr;
+        if (planted != ser_gemm_dbg_ptr) {
+            planted = ser_gemm_dbg_ptr;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(ser_gemm_dbg_dev), &planted, sizeof(void*));
+        }
+    }
+#endif
     if (a->mode == SER_MODE_FP32X) {
         // both planes share a stage: the ring doubles, so FP32X uses the two configurations that still fit 160 KiB
         if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true, true>(a, s);
