@@ -628,7 +628,7 @@ static int pick_cfg(const ser_gemm_args* a) {
     const long t256x256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
     static const long t256_min = [] {                   // tuning knob (tools/): SER_GEMM_T256_MIN=<tiles>
         const char* e = getenv("SER_GEMM_T256_MIN");
-        return e ? atol(e) : 200L;
+        return e ? atol(e) : 150L;                      // 200 before the ping-pong schedule; XLS-R-2B's QKV (184 tiles at 4 x 10 s): +3.2 % on its step
     }();
     if (a->N >= 256 && t256x256 >= t256_min) return CFG_256x256;
     // grouped positional conv: 64 output channels per group -> a 128x64 tile wastes no MFMA columns

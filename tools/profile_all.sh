@@ -19,13 +19,20 @@ stats() {  # name, bench args...
     echo "== $name: $(python3 -c "import json;d=json.load(open('$OUT/$name.json'));print(d['value'], d['unit'], d['config']['ms_per_batch'], 'ms/batch', d.get('verified'))")"
     head -8 "$f" | cut -c1-150
 }
+PMC="--steps 2 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS"
+if [ "$2" = "traffic" ]; then   # only the two traffic passes: re-stamp profiles/<tag>_pmc_traffic.json after a kernel-source change
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
+    python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|groups=2"
+    mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_pmc_* gpurun_out/profiles_$TAG/
+    echo done; exit 0
+fi
 stats wavlm_large_bf16 --steps 10 || exit 1
 stats wavlm_large_f16 --steps 10 --mode f16 || exit 1
 stats hubert_xlarge_bf16 --steps 5 --ssl_type facebook/hubert-xlarge-ll60k || exit 1
 stats xlsr_2b_bf16 --steps 5 --ssl_type facebook/wav2vec2-xls-r-2b --batch 8 || exit 1
 stats whisper_large_v3_bf16 --steps 3 --reps 4 --ssl_type openai/whisper-large-v3 --seconds 30 || exit 1
 # PMC passes: eager launches (counters are per dispatch), headline workload
-PMC="--steps 2 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|groups=2"
