@@ -568,6 +568,39 @@ def test_attention(L, mode, dh, H, bias):
     assert err < mode_tol(mode, 3e-2, 1e-4), err
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_long_utterance_bias_window(L, mode):
+    """A 22 s utterance (1100 frames, 9 query tiles) next to a short one: the bias window of a block (T + 192 distances) no longer
+    fits one staging pass of 256 threads x 4 slots, so the further passes of the copy loop run, and every query tile has its own
+    window start / alignment shift (jmin).  Same reference as test_attention."""
+    Ts, H, dh = [1100, 37], 2, 64
+    D, M, Tmax = H * dh, sum(Ts), max(Ts)
+    g = torch.Generator().manual_seed(1100)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    qa = to_act(qkv, mode)
+    qv = act_value(qa).cpu().double()
+    table = torch.randn(H, 2 * Tmax - 1, generator=g)
+    gate = torch.rand(M, H, generator=g) * 2
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    ref = torch.empty(M, D, dtype=torch.float64)
+    for b, T in enumerate(Ts):
+        blk = qv[offs[b]:offs[b + 1]]
+        q, k, v = (blk[:, i * D:(i + 1) * D].view(T, H, dh).permute(1, 0, 2) for i in range(3))
+        c = Tmax - 1
+        o = attention_reference(q, k, v, dh ** -0.5, table[:, c - (T - 1): c + T].double(), gate[offs[b]:offs[b + 1]].double())
+        ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
+    planes = 2 if mode == 2 else 1
+    out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    td, gd = table.to(DEV), gate.to(DEV)
+    L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax,
+                                td.data_ptr(), Tmax, gd.data_ptr(), out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode, 0,
+                                None, None, None, 0, stream()))
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < mode_tol(mode, 3e-2, 1e-4), err
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_attention_fused_gate_columns(L, mode):
     """WavLM gate from its two pre-activation columns per head inside the packed projection matrix."""
