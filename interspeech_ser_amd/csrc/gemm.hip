@@ -79,6 +79,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+#ifdef SER_GEMM_DBG
+    const unsigned long long dbg_e0 = __builtin_amdgcn_s_memtime();
+#endif
 
     const int ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;
@@ -199,7 +202,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         if (t < total) issue();
 
     // deferred LayerNorm: row mean / rstd of the A rows from the producer's partial sums, into the
-    // LDS words behind the ring (one row per thread; the loads fly beside the first DMA tiles)
+    // LDS words behind the ring (one row per thread; the loads fly beside the first DMA tiles.  Requesting them BEFORE
+    // the tiles -- so that they land first -- was measured and changes nothing: the reduction is short, what the block
+    // waits for is one memory round trip either way)
     float* lnst = (float*)(lds + ST * STAGE);                         // [BM][2]
     if (p.ln_stats_in) {
         for (int r = tid; r < BM; r += NT) {
@@ -363,6 +368,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         unsigned long long* d = ser_gemm_dbg_dev;
         if (d && wave == 0 && lane == 0 && blockIdx.y == 0) {
             d[blockIdx.x * 2] = t1 - dbg_t0; d[blockIdx.x * 2 + 1] = r1 - dbg_r0;
+            d[131072 + blockIdx.x * 4] = dbg_t0 - dbg_e0; d[131072 + blockIdx.x * 4 + 1] = t1;
         }
     }
 #endif
@@ -470,11 +476,32 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 cs[mi] = p.shift_const + (p.shift_in ? p.shift_in[m] : 0.f);
             }
         }
+        // The residual tile is requested a batch of 4 fragment rows at a time, BEFORE that batch's first store: the
+        // residual may be the output buffer itself (next state, written in place), so the compiler cannot move a row's
+        // loads above the previous row's stores, and the epilogue used to pay the load latency (HBM / Infinity Cache:
+        // 1-2 us) once per fragment row -- four to eight times per block.  The fragment registers of the K loop are dead
+        // here, so the 64 registers of a batch cost no occupancy.  (A lane reads and writes only its own elements: moving
+        // its loads ahead of its stores to OTHER rows cannot change what it reads.)
+        constexpr int RB = (TM * TN > 16) ? 2 : (TM < 4 ? TM : 4);          // 256x256 tile (128 accumulators): 32 registers per batch
+        f32x4 rres[RB][TN];
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
+            if (mi % RB == 0 && p.residual) {
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    int mr = m0 + wm * TM * 16 + (mi + u) * 16 + frow;
+                    mr = mr < p.M ? mr : p.M - 1;
+                    const int rr_ = p.res_row_mod ? (mr % p.res_row_mod) : mr;
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                        if (ncol0 + ni * 16 < p.N) r = *(const f32x4*)(p.residual + (int64_t)rr_ * p.ldr + gcol + ni * 16);
+                        rres[u][ni] = r;
+                    }
+                }
+            }
             const int m = m0 + wm * TM * 16 + mi * 16 + frow;
             if (m >= p.M) continue;
-            const int rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
             const int64_t orow = p.out_rowmap ? (int64_t)p.out_rowmap[m] : (int64_t)m;
             float mu = 0.f, rs = 1.f;
             if (p.ln_stats_in) {
@@ -504,10 +531,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     }
                 }
                 if (p.residual) {
-                    const float* rp = p.residual + (int64_t)rrow * p.ldr + gcol + ni * 16;
-                    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
-                    if (ok0) r0 = *(const f32x4*)rp;
-                    if (ok1) r1 = *(const f32x4*)(rp + 16);
+                    const f32x4 r0 = rres[mi % RB][ni], r1 = rres[mi % RB][ni + 1];
                     v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
                     v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
                 }
@@ -548,6 +572,15 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
         }
     }
+#ifdef SER_GEMM_DBG
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = ser_gemm_dbg_dev;
+        if (d && wave == 0 && lane == 0 && blockIdx.y == 0) d[131072 + blockIdx.x * 4 + 2] = t2;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
