@@ -445,6 +445,9 @@ def main():
                 "gemm_ms_per_batch": round(dur_ms / args.steps, 3),
                 "measured": "HIP events around every ser_gemm launch, eager pass of K batches right after the timed region "
                             "(one launch at a time: no concurrent utterance group)",
+                "clock_note": "peak is the nominal 2.4 GHz figure; a diagnostic build (tools/gemm_clock.py, profiles/r02_gemm_inkernel_clock.txt) "
+                              "stamps 1.92-1.97 GHz held inside the 256x256 K loop on random operands, where it runs at 69-73 % of the matrix "
+                              "pipe at that clock; not measured in this run",
             }
         if blocks:
             T = geo.frames_for(num_samples)
