@@ -1,6 +1,6 @@
 """Where a wave of ser_attention spends a key tile (GPU box, debug build only):
 
-    hipcc ... -DSER_ATTN_DBG -c attention.hip  ->  lib/libserhip_dbg.so ;  SER_HIP_LIB=<that> python tools/attn_phases.py [T] [bias]
+    make -C interspeech_ser_amd/csrc dbg ;  SER_HIP_LIB=$PWD/interspeech_ser_amd/lib/libserhip_dbg.so python tools/attn_phases.py [T] [bias]
 
 The debug build stamps s_memtime at six points of every tile for the four waves of block 100 and writes them to the
 buffer whose address this tool plants in the library's `ser_attn_dbg_ptr`.  Phases: issue of the next tile's global loads +

@@ -1,6 +1,6 @@
 """The clock the chip holds inside ser_gemm's K loop, and where a block spends its life (GPU box, diagnostic build only):
 
-    hipcc ... -DSER_GEMM_DBG -c gemm.hip -> lib/libserhip_dbg.so ;  SER_HIP_LIB=<that> python tools/gemm_clock.py
+    make -C interspeech_ser_amd/csrc dbg ;  SER_HIP_LIB=$PWD/interspeech_ser_amd/lib/libserhip_dbg.so python tools/gemm_clock.py
 
 MI355X_MICROARCH.md 'DVFS give-back' item 6: in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz, stamped around the
 loop after >= 2 s of back-to-back launches on random data, median over workgroups.  Printed with the K-loop rate each tile
