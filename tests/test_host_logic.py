@@ -371,3 +371,18 @@ def test_native_wav_reader_extensible_header_and_extra_chunks(tmp_path):
     p.write_bytes(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
     got = frontend.load_wav_16k(str(p))
     assert got.dtype == np.float32 and np.array_equal(got, pcm.astype(np.float32) / 32768.0)
+
+
+def test_pretrained_entry_points_demand_a_checkpoint():
+    """preprocessing/preprocess_{speech,whisper}_pretrained.py: the reference hard-codes the fine-tuned checkpoint's path
+    (preprocess_speech_pretrained.py:170, preprocess_whisper_pretrained.py:183); here it is an argument, and leaving it out
+    stops the script before any model is built -- with the reference's closing line and its exit status 0."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script in ("preprocess_speech_pretrained.py", "preprocess_whisper_pretrained.py"):
+        r = subprocess.run([sys.executable, os.path.join(root, "preprocessing", script), "--ssl_type", "anything",
+                            "--wav_dir", "/nonexistent", "--save_path", "/nonexistent"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (script, r.stderr[-400:])
+        assert "--checkpoint" in r.stdout and "Something went wrong" in r.stdout, (script, r.stdout)
