@@ -25,7 +25,7 @@
 //     of tiles that share activation panels.
 #include "ser_common.h"
 #ifndef SER_GEMM_PP
-#define SER_GEMM_PP 3        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
+#define SER_GEMM_PP 11        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile, 8 = the FP32X 128x128 tile, 16 = the FP32X 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
 #endif
 #include <stdlib.h>
 #include <stdio.h>
@@ -244,9 +244,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #ifdef SER_GEMM_DBG
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    constexpr int PP_BIT = LNEPI ? 4 : (TM * TN >= 32 ? 1 : 2);
-    constexpr bool PP = (SER_GEMM_PP & PP_BIT) && NW == 8 && NPL == 1 && KS == 2;
-    constexpr int PH = (TM * TN >= 32) ? KS : 1;                      // read phases per K tile
+    constexpr int PP_BIT = NPL == 2 ? (LNEPI ? 16 : 8) : (LNEPI ? 4 : (TM * TN >= 32 ? 1 : 2));
+    constexpr bool PP = (SER_GEMM_PP & PP_BIT) && NW == 8 && (KS == 2 || NPL == 2);
+    constexpr int PH = (NPL == 1 && TM * TN >= 32) ? KS : 1;          // read phases per K tile (FP32X: 12 fragments + 24 MFMAs per k-step, one phase)
     constexpr int SPP = KS / PH;                                      // k-steps per phase
     if constexpr (PP) {
         const int late = wave >> 2;
@@ -264,12 +264,19 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #pragma unroll
             for (int ph = 0; ph < PH; ++ph) {
                 bf16x8 af[SPP][TM], wf[SPP][TN];
+                bf16x8 al[NPL == 2 ? SPP : 1][NPL == 2 ? TM : 1], wl[NPL == 2 ? SPP : 1][NPL == 2 ? TN : 1];   // FP32X: the lo planes
 #pragma unroll
                 for (int u = 0; u < SPP; ++u) {
 #pragma unroll
-                    for (int x = 0; x < TM; ++x) af[u][x] = *(const bf16x8*)(sb + offA[ph * SPP + u] + x * 16 * ROWB);
+                    for (int x = 0; x < TM; ++x) {
+                        af[u][x] = *(const bf16x8*)(sb + offA[ph * SPP + u] + x * 16 * ROWB);
+                        if constexpr (NPL == 2) al[u][x] = *(const bf16x8*)(sb + offA[ph * SPP + u] + A_BYTES + x * 16 * ROWB);
+                    }
 #pragma unroll
-                    for (int x = 0; x < TN; ++x) wf[u][x] = *(const bf16x8*)(sb + offW[ph * SPP + u] + x * 16 * ROWB);
+                    for (int x = 0; x < TN; ++x) {
+                        wf[u][x] = *(const bf16x8*)(sb + offW[ph * SPP + u] + x * 16 * ROWB);
+                        if constexpr (NPL == 2) wl[u][x] = *(const bf16x8*)(sb + offW[ph * SPP + u] + W_BYTES + x * 16 * ROWB);
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (ph == PH - 1 && late) { if (more) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>(); }
@@ -282,8 +289,15 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < TM; ++mi)
-                            acc[ni][mi] = mfma16<MODE>(wf[u][ni], af[u][mi], acc[ni][mi]);
+                        for (int mi = 0; mi < TM; ++mi) {
+                            if constexpr (NPL == 2) {                     // same product order as the plain ring: lo*hi, hi*lo, hi*hi
+                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[u][ni], af[u][mi], acc[ni][mi], 0, 0, 0);
+                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][ni], al[u][mi], acc[ni][mi], 0, 0, 0);
+                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][ni], af[u][mi], acc[ni][mi], 0, 0, 0);
+                            } else {
+                                acc[ni][mi] = mfma16<MODE>(wf[u][ni], af[u][mi], acc[ni][mi]);
+                            }
+                        }
                 __builtin_amdgcn_s_setprio(0);
                 if (ph == PH - 1 && !late) { if (more) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>(); }
                 __builtin_amdgcn_sched_barrier(0);
