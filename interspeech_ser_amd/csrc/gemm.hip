@@ -734,6 +734,11 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->mode == SER_MODE_FP32X) {
         // both planes share a stage: the ring doubles, so FP32X uses the two configurations that still fit 160 KiB
         if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true, true>(a, s);
+        // Large grids: 256x128 tiles of 64x64 wave tiles on a 32-deep, 3-stage ring (144 KiB): 16 fragments feed 48 MFMAs per
+        // k-step (0.33 LDS fragment reads per MFMA against 0.5 for the 32x64 wave tile below), one ping-pong phase per K tile
+        static const long x32_256_min = [] { const char* e = getenv("SER_GEMM_X32_256_MIN"); return e ? atol(e) : 100L; }();   // 100: M = 3992 out-proj / FC2 (128 tiles) gain, M = 1996 ones (64 tiles) lose
+        const long t256x128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128) * a->groups;
+        if (x32_256_min > 0 && a->N >= 128 && t256x128 >= x32_256_min) return launch_cfg<4, 2, 4, 4, 32, 3, false, true>(a, s);
         return launch_cfg<4, 2, 2, 4, 64, 2, false, true>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
     }
     switch (pick_cfg(a)) {

@@ -135,6 +135,20 @@ def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
     assert torch.equal(out.cpu().double(), ref)
 
 
+def test_gemm_fp32x_large_grid_tile_integer_exact(L):
+    """FP32X launches with >= 100 tiles of 256 x 128 take the 256x128 / BK = 32 / 3-stage ping-pong tile (gemm.hip, ser_gemm): ragged M
+    and N edges, K = 64..320 (ring fill and drain at 2..10 K tiles), integer operands so that one misplaced fragment shows."""
+    for M, N, K in ((2561, 1288, 192), (2700, 1536, 64), (3000, 1160, 320)):
+        assert ((M + 255) // 256) * ((N + 127) // 128) >= 100
+        g = torch.Generator().manual_seed(M + N)
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        W = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()
+        bias = torch.randint(-4, 5, (N,), generator=g).float()
+        ref = A.double() @ W.double().T + bias.double()
+        out, _ = run_gemm(L, to_act(A, 2), to_act(W, 2), M, N, K, 2, bias=bias.to(DEV))
+        assert torch.equal(out.cpu().double(), ref), (M, N, K)
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K,bias", [(300, 512, 192, True), (1000, 512, 1536, False), (77, 64, 128, True),
                                         (13001, 512, 128, True), (25999, 512, 64, False)])
