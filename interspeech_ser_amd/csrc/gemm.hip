@@ -25,7 +25,7 @@
 //     of tiles that share activation panels.
 #include "ser_common.h"
 #ifndef SER_GEMM_PP
-#define SER_GEMM_PP 11        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile, 8 = the FP32X 128x128 tile, 16 = the FP32X 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
+#define SER_GEMM_PP 27        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile, 8 = the FP32X 128x128 tile, 16 = the FP32X 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
 #endif
 #include <stdlib.h>
 #include <stdio.h>
@@ -248,7 +248,64 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr bool PP = (SER_GEMM_PP & PP_BIT) && NW == 8 && (KS == 2 || NPL == 2);
     constexpr int PH = (NPL == 1 && TM * TN >= 32) ? KS : 1;          // read phases per K tile (FP32X: 12 fragments + 24 MFMAs per k-step, one phase)
     constexpr int SPP = KS / PH;                                      // k-steps per phase
-    if constexpr (PP) {
+    // FP32X tiles with 64x128 wave tiles (the LayerNorm tile: one k-step per 32-deep K tile, 24 fragments, 96 MFMAs): the two read
+    // phases of a K tile are the two halves of the weight fragments (the activation fragments stay in registers across them), so
+    // 64 fragment registers are live beside the 128 accumulators instead of 96
+    constexpr bool PPW = PP && NPL == 2 && KS == 1 && TN >= 8;
+    if constexpr (PPW) {
+        constexpr int TNH = TN / 2;
+        const int late = wave >> 2;
+        if (total >= ST - 1) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (late) __builtin_amdgcn_s_barrier();
+        int stage = 0;
+        for (int kt = 0; kt < total; ++kt) {
+            const bool more = kt + ST - 1 < total;
+            if (more) issue();
+            const char* sb = lds + stage * STAGE;
+            stage = (stage + 1 == ST) ? 0 : stage + 1;
+            const bool last = kt + 1 == total;
+            bf16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                bf16x8 wh[TNH], wl[TNH];
+                if (ph == 0) {
+#pragma unroll
+                    for (int x = 0; x < TM; ++x) {
+                        ah[x] = *(const bf16x8*)(sb + offA[0] + x * 16 * ROWB);
+                        al[x] = *(const bf16x8*)(sb + offA[0] + A_BYTES + x * 16 * ROWB);
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < TNH; ++x) {
+                    wh[x] = *(const bf16x8*)(sb + offW[0] + (ph * TNH + x) * 16 * ROWB);
+                    wl[x] = *(const bf16x8*)(sb + offW[0] + W_BYTES + (ph * TNH + x) * 16 * ROWB);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ph == 1 && late) { if (more) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int nj = 0; nj < TNH; ++nj)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const int ni = ph * TNH + nj;
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nj], ah[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nj], al[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nj], ah[mi], acc[ni][mi], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                if (ph == 1 && !late) { if (more) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ph == 1 && last && late)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if constexpr (PP && !PPW) {
         const int late = wave >> 2;
         if (total >= ST - 1) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>();    // fewer tiles in flight when K is short
         __builtin_amdgcn_s_barrier();                                 // tile 0 is visible to every wave
