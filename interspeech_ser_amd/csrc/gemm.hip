@@ -791,6 +791,10 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->mode == SER_MODE_FP32X) {
         // both planes share a stage: the ring doubles, so FP32X uses the two configurations that still fit 160 KiB
         if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true, true>(a, s);
+        // grouped positional conv (<= 64 output channels per group): 128x64 tiles of 32x64 wave tiles, like the bf16 path's -- the
+        // 128x128 tile below computes 64 dead columns per group (fp32x pos-conv: 360 us against 100 us in bf16)
+        static const int x32_n64 = [] { const char* e = getenv("SER_GEMM_N64"); return e ? atoi(e) : 1; }();
+        if (x32_n64 && a->N <= 64) return launch_cfg<4, 1, 2, 4, 32, 2, false, true>(a, s);
         // Large grids: 256x128 tiles of 64x64 wave tiles on a 32-deep, 3-stage ring (144 KiB): 16 fragments feed 48 MFMAs per
         // k-step (0.33 LDS fragment reads per MFMA against 0.5 for the 32x64 wave tile below), one ping-pong phase per K tile
         static const long x32_256_min = [] { const char* e = getenv("SER_GEMM_X32_256_MIN"); return e ? atol(e) : 100L; }();   // 100: M = 3992 out-proj / FC2 (128 tiles) gain, M = 1996 ones (64 tiles) lose
