@@ -234,8 +234,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--max_len", type=int, default=80, help="tokens per text (roberta workloads)")
     ap.add_argument("--ssl_type", type=str, default="microsoft/wavlm-large")
-    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x", "f16"])
-    ap.add_argument("--parity-mode", type=str, default="f16,fp32x",
+    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x", "f16", "f16q", "f16a"])
+    ap.add_argument("--parity-mode", type=str, default="f16a,f16q,f16,fp32x",
                     help="numerics mode(s) of the parity records, comma separated: the first fills `parity_mode`, "
                          "the others `parity_mode_<name>`")
     ap.add_argument("--layers", type=int, default=0, help="debug: truncate the encoder (invalidates the metric)")
@@ -411,7 +411,8 @@ def main():
         total_utts = args.batch * reps * args.steps * world
         value = total_utts / elapsed
         gf_utt = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
-        dtype_name = {"bf16": "bf16", "fp32x": "bf16x3 (fp32-grade split)", "f16": "f16 (fp32x stem)"}
+        dtype_name = {"bf16": "bf16", "fp32x": "bf16x3 (fp32-grade split)", "f16": "f16 (fp32x stem)",
+                      "f16q": "f16 (fp32x stem, f16x3 logit path)", "f16a": "f16 (fp32x stem, f16x3 attention block)"}
         out = {
             "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract" if geo is C.WAVLM_LARGE and abs(args.seconds - 10) < 1e-6
                       else f"utterances/sec ({args.seconds:.0f} s @16 kHz) {geo.name} embed extract",
@@ -446,7 +447,7 @@ def main():
                         break
             n = len(trace)
             achieved = flops / (dur_ms * 1e-3) / 1e12
-            mult = 3.0 if args.mode == "fp32x" else 1.0
+            mult = 3.0 if args.mode == "fp32x" else 1.0        # (f16 / f16q: 3 in the stem and, for f16q, in the q / k projection)
             out["roofline"] = {
                 "kernel": "ser_gemm_kernel (bf16 MFMA implicit-conv GEMM + fused epilogue)",
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -498,12 +499,16 @@ def main():
             first = [a for a, _ in spans]                                 # first utterance of every group
             ref = oracle_states(geo, sd, waves[0], whisper)               # CPU oracle on utterance 0 (full geometry, T frames)
             err_m = max(rel_err(hs_timed[0].utterance(0, l).cpu(), r) for l, r in enumerate(ref))
-            bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3}[args.mode]
+            bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3, "f16q": 1e-3, "f16a": 1e-3}[args.mode]
             verification.update({"timed_mode": args.mode, "timed_mode_max_rel_err_vs_oracle": float(f"{err_m:.3e}"),
                                  "timed_mode_bound": bound, "utterances_vs_parity_mode": first})
             checks_ok = checks_ok and err_m <= bound
             what = {"fp32x": "bf16 x3 split (hi*hi + lo*hi + hi*lo) everywhere",
                     "f16": "fp32x conv stem (conv stack, projection, positional conv) + fp16 single-product encoder layers",
+                    "f16a": "fp32x conv stem; packed QKV projection, attention (S = K Q^T, P V) and output projection on the 3-product "
+                            "split over fp16 hi + lo planes; FC1 / FC2 (62 % of the layer FLOPs) single-product fp16",
+                    "f16q": "f16 with the logit path fp32-grade: q / k (+ gate) columns of the packed projection and S = K Q^T on the "
+                            "3-product split over fp16 hi + lo planes; v, P V, output projection and feed-forward single-product fp16",
                     "bf16": "bf16 single product everywhere"}
             for idx, pmode in enumerate(m for m in args.parity_mode.split(",") if m):
                 if pmode == args.mode:

@@ -23,7 +23,7 @@
  *     whose utterance b owns rows frame_offs[b] .. frame_offs[b+1]-1;
  *   - "act" tensors feed matrix-core GEMMs: bf16, row-major, 1 plane (SER_MODE_BF16) or
  *     2 planes hi/lo with x ~= hi + lo (SER_MODE_FP32X, the 3-product split that gives
- *     fp32-grade results on the bf16 MFMA pipe), or 1 plane of fp16 (SER_MODE_FP16);
+ *     fp32-grade results on the bf16 MFMA pipe), 1 plane of fp16 (SER_MODE_FP16) or 2 planes of fp16 (SER_MODE_FP16X);
  *     plane p lives at base + p*plane_stride;
  *   - the residual stream / hidden states are fp32 row-major [rows, D].
  */
@@ -37,13 +37,22 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 10
+#define SER_ABI_VERSION 11
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
 #define SER_MODE_FP16  3   /* act tensors have 1 plane of IEEE fp16 (11 significand bits, saturated at +-65504);
                             * GEMMs do 1 f16 MFMA product -- same rate as bf16, 8x finer operand rounding.  The host
                             * runs the conv stem in FP32X and the encoder layers in FP16 ("f16" numerics mode) */
+#define SER_MODE_FP16X 4   /* act tensors have 2 planes of IEEE fp16, x ~= hi + lo (22 significand bits; hi is exactly the FP16 copy, so
+                            * a single-product FP16 launch may read plane 0 of an FP16X tensor); GEMMs and ser_attention do
+                            * hi*hi + lo*hi + hi*lo on the f16 MFMA.  The host's "f16a" numerics mode runs the whole ATTENTION BLOCK of
+                            * every encoder layer in it (packed projection, attention, output projection) and the feed-forward pair in
+                            * FP16; "f16q" only the LOGIT path -- the q / k (+ WavLM gate) columns of the packed projection and, through
+                            * SER_MODE_FP16Q, S = K Q^T: a softmax weight moves by (logit error) * ln 2, so the attention block is where
+                            * single-product rounding is amplified (reference arithmetic is fp32: preprocess_speech.py:50,66) */
+#define SER_MODE_FP16Q 5   /* ser_attention only: q and k are FP16X column blocks (3-product S = K Q^T), v is read from plane 0 and
+                            * P V runs single fp16 products; the output is a single-plane FP16 tensor */
 
 #define SER_ACT_NONE 0
 #define SER_ACT_GELU 1     /* exact erf GELU (ACT2FN["gelu"]) */
@@ -144,7 +153,10 @@ typedef struct ser_gemm_args {
     float*         shift_out;      /* [M] or NULL (no shifting) */
     float          shift_const;
     int32_t        out_mode;       /* format of out_act: 0 = mode; SER_MODE_FP16 with mode == SER_MODE_FP32X converts (one plane of
-                                    * fp16 written from a 3-product GEMM: the stem -> layers boundary of the host's "f16" mode) */
+                                    * fp16 written from a 3-product GEMM: the stem -> layers boundary of the host's "f16" mode);
+                                    * SER_MODE_FP16X with mode == SER_MODE_FP16 writes hi + lo fp16 planes from a single-product
+                                    * GEMM (FC2 -> the next layer's packed projection in the "f16q" / "f16a" modes); SER_MODE_FP16 with
+                                    * mode == SER_MODE_FP16X writes one plane from a 3-product GEMM (output projection -> FC1, "f16a") */
     const float*   ln_shift;       /* [M] shift of the A rows / their partials (consumer), or NULL */
     float*         mean_out;       /* [M] absolute row mean of the A rows (consumer), or NULL */
 } ser_gemm_args;

@@ -18,11 +18,13 @@ LIB_PATH = os.environ.get("SER_HIP_LIB") or os.path.join(_HERE, "lib", "libserhi
 MODE_BF16 = 1
 MODE_FP32X = 2
 MODE_FP16 = 3
+MODE_FP16X = 4
+MODE_FP16Q = 5
 ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
 WS_WAVE_FRAMES = 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

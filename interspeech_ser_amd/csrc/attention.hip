@@ -87,19 +87,24 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 #endif
 // B2D: dense additive bias from global memory instead of the relative-position table (needs PRE, excludes TBL).
 template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && MODE == SER_MODE_FP32X) ? 1 : ((DHP == 64 && MODE != SER_MODE_FP32X) ? SER_ATTN_MINW : 2)))
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && mode_traits<MODE>::planes == 2) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2)))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
-    constexpr int NP = (MODE == SER_MODE_FP32X) ? 2 : 1;
+    // NP: planes of Q and K (the logit path S = K Q^T: 3 products when 2), NPV: planes of V and P.  FP16Q (the "f16q" numerics
+    // mode) keeps the logits fp32-grade -- q, k arrive as fp16 hi + lo planes -- and runs P V on single fp16 products; its
+    // output is the single-plane FP16 operand of the output projection.  FP16X ("f16a") splits everything, like FP32X.
+    constexpr int NP = mode_traits<MODE>::planes;
+    constexpr int NPV = (MODE == SER_MODE_FP32X || MODE == SER_MODE_FP16X) ? 2 : 1;
+    constexpr int OUTM = (MODE == SER_MODE_FP16Q) ? SER_MODE_FP16 : MODE;
     constexpr int RS = DHP * 2;                 // LDS row bytes
     constexpr int KS = DHP / 16;                // QK^T k-steps
     constexpr int DSUB = DHP / 32;              // 32-wide output column blocks
     constexpr int CPR = DHP / 8;                // 16-byte chunks per row
     constexpr int TILE = ABKV * RS;             // bytes of one K or V plane tile
     constexpr int NCH = ABKV * CPR / NT;        // staged 16-B chunks per thread per plane per operand
-    constexpr bool DB = (NCH * 2 * NP) <= 8;    // double-buffer when the register stage is <= 32 VGPRs
+    constexpr bool DB = (NCH * (NP + NPV)) <= 8;   // double-buffer when the register stage is <= 32 VGPRs
     constexpr int NBUF = DB ? 2 : 1;
-    constexpr int BUF = 2 * NP * TILE;          // one K+V buffer
+    constexpr int BUF = (NP + NPV) * TILE;      // one K+V buffer
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ldsB = (float*)(smem + NBUF * BUF);
 
@@ -162,13 +167,14 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 u32x4 kv = *(const u32x4*)(src + p.k_col + pl * p.plane);
-                u32x4 vv = *(const u32x4*)(src + p.v_col + pl * p.plane);
+                u32x4 vv = {0u, 0u, 0u, 0u};
+                if (pl < NPV) vv = *(const u32x4*)(src + p.v_col + pl * p.plane);
                 if (masked) {                                    // wave-uniform: only ragged tiles / padded head dims
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { kv[e] &= keep; vv[e] &= keep; }
                 }
                 stg[pl][0][i] = kv;
-                stg[pl][1][i] = vv;
+                if (pl < NPV) stg[pl][1][i] = vv;
             }
         }
     };
@@ -181,7 +187,8 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 *(u32x4*)(base + pl * TILE + key * RS + (k_swz<DHP>(key, ch) << 4)) = stg[pl][0][i];
-                *(u32x4*)(base + NP * TILE + pl * TILE + key * RS + (v_unit_swz<DHP>(key, ch >> 2) << 6) + ((ch & 3) << 4)) = stg[pl][1][i];
+                if (pl < NPV)
+                    *(u32x4*)(base + NP * TILE + pl * TILE + key * RS + (v_unit_swz<DHP>(key, ch >> 2) << 6) + ((ch & 3) << 4)) = stg[pl][1][i];
             }
         }
     };
@@ -245,7 +252,7 @@ void attention_kernel(const AttnParams p) {
             // gate pre-activations ride along as two extra columns per head of the packed projection
             const unsigned short* gp = p.qkv + (int64_t)(row0 + qc) * p.ld + p.gate_col + 2 * h;
             g_in0 = elem2f<MODE>(gp[0]); g_in1 = elem2f<MODE>(gp[1]);
-            if (NP == 2) { g_in0 += bf2f(gp[p.plane]); g_in1 += bf2f(gp[p.plane + 1]); }
+            if (NP == 2) { g_in0 += elem2f<MODE>(gp[p.plane]); g_in1 += elem2f<MODE>(gp[p.plane + 1]); }
             g_c = p.gru_const[h];
         }
     }
@@ -381,8 +388,8 @@ void attention_kernel(const AttnParams p) {
                     st[sub] = mfma32<MODE>(kh, qf[0][ks], st[sub]);
                     if (NP == 2) {
                         const bf16x8 kl = *(const bf16x8*)(ldsK + TILE + off);
-                        st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ks], st[sub], 0, 0, 0);
-                        st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[NP - 1][ks], st[sub], 0, 0, 0);
+                        st[sub] = mfma32<MODE>(kl, qf[0][ks], st[sub]);
+                        st[sub] = mfma32<MODE>(kh, qf[NP - 1][ks], st[sub]);
                     }
                 }
             }
@@ -453,15 +460,17 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 ph, plo;
-                if constexpr (MODE == SER_MODE_FP16) {
-                    f16x8 p16;                                       // P in [0, 1]: no saturation needed
+                if constexpr (mode_traits<MODE>::f16) {
+                    f16x8 p16, p16lo;                                // P in [0, 1]: no saturation needed
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float e = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
                         lsum += e;
                         p16[j] = (_Float16)e;
+                        if (NPV == 2) p16lo[j] = (_Float16)(e - (float)p16[j]);
                     }
                     ph = __builtin_bit_cast(bf16x8, p16);
+                    if (NPV == 2) plo = __builtin_bit_cast(bf16x8, p16lo);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -469,7 +478,7 @@ void attention_kernel(const AttnParams p) {
                         lsum += e;
                         const __bf16 hi = (__bf16)e;
                         ph[j] = hi;
-                        if (NP == 2) plo[j] = (__bf16)(e - (float)hi);
+                        if (NPV == 2) plo[j] = (__bf16)(e - (float)hi);
                     }
                 }
 #pragma unroll
@@ -478,10 +487,10 @@ void attention_kernel(const AttnParams p) {
                     if constexpr (WIDE) vh = vfr[sub][s2][ds];
                     else vh = v_frag(ldsV, sub, s2, ds);
                     ot[ds] = mfma32<MODE>(vh, ph, ot[ds]);
-                    if (NP == 2) {
+                    if (NPV == 2) {
                         const bf16x8 vl = v_frag(ldsV + TILE, sub, s2, ds);
-                        ot[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[ds], 0, 0, 0);
-                        ot[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, plo, ot[ds], 0, 0, 0);
+                        ot[ds] = mfma32<MODE>(vl, ph, ot[ds]);
+                        ot[ds] = mfma32<MODE>(vh, plo, ot[ds]);
                     }
                 }
             }
@@ -533,7 +542,7 @@ void attention_kernel(const AttnParams p) {
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int d = ds * 32 + 8 * r4 + 4 * hh;
                 if (d < dh)
-                    store_act4<MODE>(orow + d, p.out_plane, ot[ds][4 * r4] * inv, ot[ds][4 * r4 + 1] * inv,
+                    store_act4<OUTM>(orow + d, p.out_plane, ot[ds][4 * r4] * inv, ot[ds][4 * r4 + 1] * inv,
                                      ot[ds][4 * r4 + 2] * inv, ot[ds][4 * r4 + 3] * inv);
             }
     }
@@ -561,26 +570,27 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
     if ((ld % 8) || (ldo % 4) || (q_col % 8) || (k_col % 8) || (v_col % 8)) return ser_fail(-4, "ser_attention: misaligned pitches/columns");
-    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X && mode != SER_MODE_FP16) return ser_fail(-5, "ser_attention: bad mode %d", mode);
+    if (mode < SER_MODE_BF16 || mode > SER_MODE_FP16Q) return ser_fail(-5, "ser_attention: bad mode %d", mode);
     if ((table != nullptr) != (gate != nullptr || gru_const != nullptr))
         return ser_fail(-6, "ser_attention: the bias table needs a gate (gate[] or gate_col + gru_const) and vice versa");
     if (gate && gru_const) return ser_fail(-9, "ser_attention: give gate[] or gru_const, not both");
     if (gru_const && (gate_col < 0 || (gate_col % 2))) return ser_fail(-10, "ser_attention: bad gate_col %d", gate_col);
     if (table && table_T < max_frames) return ser_fail(-7, "ser_attention: bias table built for T=%d < max_frames=%d", table_T, max_frames);
     if (bias2d) {
-        if (table || !key_lens || scale > 0.f || dh > 64 || mode == SER_MODE_FP16)
+        if (table || !key_lens || scale > 0.f || dh > 64 || mode == SER_MODE_FP16 || mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q)
             return ser_fail(-11, "ser_attention: bias2d needs key_lens, a pre-scaled q (scale <= 0), dh <= 64, no table, bf16 / fp32x");
         if (bias2d_ld < max_frames || (bias2d_ld % ABKV))
             return ser_fail(-12, "ser_attention: bias2d_ld=%lld must be a multiple of %d and >= max_frames", (long long)bias2d_ld, ABKV);
     }
     const int dhp = dh <= 64 ? 64 : 128;
-    const int np = mode == SER_MODE_FP32X ? 2 : 1;
+    const int np = (mode == SER_MODE_FP32X || mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q) ? 2 : 1;      // planes of q / k
+    const int npv = (mode == SER_MODE_FP32X || mode == SER_MODE_FP16X) ? 2 : 1;                                 // planes of v
     // 8-wave blocks: -1.1 us per launch in isolation (24.4 -> 23.3 us at 8 x 499 frames), +1.2 % on the real step
     // (512-thread blocks leave no room for the other utterance group's blocks on the CU): off unless SER_ATTN_W8=1
     static const int w8_knob = [] { const char* e = getenv("SER_ATTN_W8"); return e ? atoi(e) : 0; }();
     const int nwv = (w8_knob && mode == SER_MODE_BF16 && dhp == 64 && max_frames > ABQ) ? 8 : 4;
     const int nch = ABKV * (dhp / 8) / (64 * nwv);
-    const int nbuf = (nch * 2 * np <= 8) ? 2 : 1;
+    const int nbuf = (nch * (np + npv) <= 8) ? 2 : 1;
     // copy stride == 16 (mod 64) floats: the 4 shifted copies x the 4 query phases of a ds_read_b128
     // lane group then land on 16 distinct 4-bank slots (a multiple of 64 made them 2-way conflicts)
     int bias_stride = 0;
@@ -588,7 +598,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
         bias_stride = ((max_frames + 32 * nwv + 2 * ABKV + 3 + 4) / 4) * 4;   // window of one query block (+ the 0..3 alignment slots), not all 2T-1 distances
         bias_stride += (16 - (bias_stride & 63) + 64) & 63;
     }
-    const size_t lds = (size_t)nbuf * 2 * np * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
+    const size_t lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
     if (lds > 160 * 1024) return ser_fail(-8, "ser_attention: LDS need %zu > 160 KiB (max_frames=%d)", lds, max_frames);
     AttnParams p;
     p.qkv = (const unsigned short*)qkv; p.ld = ld; p.plane = plane_stride;
@@ -614,6 +624,13 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
         return pre ? (table ? launch_attention<64, SER_MODE_BF16, true, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, true, false, 8>(p, grid, lds, s))
                    : (table ? launch_attention<64, SER_MODE_BF16, false, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, false, false, 8>(p, grid, lds, s));
     if (mode == SER_MODE_FP16) return dhp == 64 ? SER_ATTN(64, SER_MODE_FP16) : SER_ATTN(128, SER_MODE_FP16);
+    if (mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q) {      // "f16a" / "f16q": the host always pre-scales q; only the PRE forms are built
+        if (!pre) return ser_fail(-13, "ser_attention: FP16X / FP16Q need a pre-scaled q (scale <= 0)");
+#define SER_ATTN_X(D_, M_) (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s))
+        if (mode == SER_MODE_FP16X) return dhp == 64 ? SER_ATTN_X(64, SER_MODE_FP16X) : SER_ATTN_X(128, SER_MODE_FP16X);
+        return dhp == 64 ? SER_ATTN_X(64, SER_MODE_FP16Q) : SER_ATTN_X(128, SER_MODE_FP16Q);
+#undef SER_ATTN_X
+    }
     if (dhp == 64 && np == 1) return SER_ATTN(64, SER_MODE_BF16);
     if (dhp == 64) return SER_ATTN(64, SER_MODE_FP32X);
     if (np == 1) return SER_ATTN(128, SER_MODE_BF16);

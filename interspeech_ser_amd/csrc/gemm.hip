@@ -67,7 +67,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     // FP32X: both planes (hi, lo) of the A and W tiles of a K tile sit in one stage, fetched ONCE, and every
     // fragment pair feeds 3 MFMAs (hi*hi, lo*hi, hi*lo): 2x the L2->LDS bytes of bf16 for 3x the products,
     // instead of three full passes over K
-    constexpr int NPL = (MODE == SER_MODE_FP32X) ? 2 : 1;
+    constexpr int NPL = mode_traits<MODE>::planes;               // FP32X (bf16 hi/lo) and FP16X (fp16 hi/lo)
     constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = NPL * (A_BYTES + W_BYTES);
     constexpr int LA = BM / RPP / NW, LW = BN / RPP / NW;       // DMA pieces per wave per K tile
     constexpr int LPT = NPL * (LA + LW);
@@ -293,9 +293,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi) {
                         const int ni = ph * TNH + nj;
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nj], ah[mi], acc[ni][mi], 0, 0, 0);
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nj], al[mi], acc[ni][mi], 0, 0, 0);
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nj], ah[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = mfma16<MODE>(wl[nj], ah[mi], acc[ni][mi]);
+                        acc[ni][mi] = mfma16<MODE>(wh[nj], al[mi], acc[ni][mi]);
+                        acc[ni][mi] = mfma16<MODE>(wh[nj], ah[mi], acc[ni][mi]);
                     }
                 __builtin_amdgcn_s_setprio(0);
                 if (ph == 1 && !late) { if (more) wait_vmcnt<LPT * (ST - 2)>(); else wait_vmcnt<0>(); }
@@ -348,9 +348,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #pragma unroll
                         for (int mi = 0; mi < TM; ++mi) {
                             if constexpr (NPL == 2) {                     // same product order as the plain ring: lo*hi, hi*lo, hi*hi
-                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[u][ni], af[u][mi], acc[ni][mi], 0, 0, 0);
-                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][ni], al[u][mi], acc[ni][mi], 0, 0, 0);
-                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][ni], af[u][mi], acc[ni][mi], 0, 0, 0);
+                                acc[ni][mi] = mfma16<MODE>(wl[u][ni], af[u][mi], acc[ni][mi]);
+                                acc[ni][mi] = mfma16<MODE>(wf[u][ni], al[u][mi], acc[ni][mi]);
+                                acc[ni][mi] = mfma16<MODE>(wf[u][ni], af[u][mi], acc[ni][mi]);
                             } else {
                                 acc[ni][mi] = mfma16<MODE>(wf[u][ni], af[u][mi], acc[ni][mi]);
                             }
@@ -423,9 +423,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi) {
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = mfma16<MODE>(wl[ni], ah[mi], acc[ni][mi]);
+                        acc[ni][mi] = mfma16<MODE>(wh[ni], al[mi], acc[ni][mi]);
+                        acc[ni][mi] = mfma16<MODE>(wh[ni], ah[mi], acc[ni][mi]);
                     }
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -670,26 +670,41 @@ static hipError_t launch_mode(const ser_gemm_args* a, dim3 grid, dim3 block, int
     return hipSuccess;
 }
 
-// X32: the configuration serves FP32X (two planes per stage); otherwise the single-plane modes BF16 / FP16.
+// X32: the configuration serves the two-plane modes FP32X / FP16X (both planes per stage); otherwise the single-plane modes BF16 / FP16.
 template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI, bool X32 = false>
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    const int npl = (a->mode == SER_MODE_FP32X) ? 2 : 1;
+    const int npl = (a->mode == SER_MODE_FP32X || a->mode == SER_MODE_FP16X) ? 2 : 1;
     const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8);   // ring (+ [BM][2] row statistics)
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     hipError_t e = hipSuccess;
     if constexpr (X32) {
         if constexpr (!LNEPI) {
-            if (a->out_mode == SER_MODE_FP16)          // stem -> layers boundary of the "f16" numerics mode
+            if (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16)      // output projection of "f16a": 3 products, one-plane copy for FC1
+                e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16X, LNEPI, SER_MODE_FP16>(a, grid, block, LDS, s);
+            else if (a->mode == SER_MODE_FP16X)        // attention block ("f16a") / logit path ("f16q"): 3 products on the f16 MFMA
+                e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16X, LNEPI>(a, grid, block, LDS, s);
+            else if (a->out_mode == SER_MODE_FP16)     // stem -> layers boundary of the "f16" numerics mode
                 e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI, SER_MODE_FP16>(a, grid, block, LDS, s);
             else
                 e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>(a, grid, block, LDS, s);
         } else {
+            if (a->mode == SER_MODE_FP16X) return ser_fail(-22, "ser_gemm: the LayerNorm epilogue has no FP16X form");
             e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>(a, grid, block, LDS, s);
         }
     } else {
-        if (a->mode == SER_MODE_FP16) e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16, LNEPI>(a, grid, block, LDS, s);
+        if (a->mode == SER_MODE_FP16) {
+            if constexpr (!LNEPI && BN >= 128) {
+                if (a->out_mode == SER_MODE_FP16X)     // FC2 of the "f16q" mode: the next layer's q / k projection reads hi + lo planes
+                    e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16, LNEPI, SER_MODE_FP16X>(a, grid, block, LDS, s);
+                else
+                    e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16, LNEPI>(a, grid, block, LDS, s);
+            } else {
+                if (a->out_mode == SER_MODE_FP16X) return ser_fail(-22, "ser_gemm: FP16 -> FP16X output needs a dense tile (N > 64, no LayerNorm epilogue)");
+                e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16, LNEPI>(a, grid, block, LDS, s);
+            }
+        }
         else e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_BF16, LNEPI>(a, grid, block, LDS, s);
     }
     if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
@@ -753,7 +768,8 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->K % 64) return ser_fail(-3, "ser_gemm: K=%d must be a multiple of 64", a->K);
     if (a->kc && (a->kc % 64 || a->K % a->kc)) return ser_fail(-4, "ser_gemm: kc=%d must divide K and be a multiple of 64", a->kc);
     if (a->N % 8) return ser_fail(-5, "ser_gemm: N=%d must be a multiple of 8", a->N);
-    if (a->mode != SER_MODE_BF16 && a->mode != SER_MODE_FP32X && a->mode != SER_MODE_FP16) return ser_fail(-6, "ser_gemm: bad mode %d", a->mode);
+    if (a->mode != SER_MODE_BF16 && a->mode != SER_MODE_FP32X && a->mode != SER_MODE_FP16 && a->mode != SER_MODE_FP16X)
+        return ser_fail(-6, "ser_gemm: bad mode %d", a->mode);
     if (!a->a_rowoff && (a->lda % 8)) return ser_fail(-7, "ser_gemm: lda must be a multiple of 8");
     if (a->groups < 1) return ser_fail(-8, "ser_gemm: groups=%d", a->groups);
     if (!a->out_f32 && !a->out_act) return ser_fail(-9, "ser_gemm: no output");
@@ -772,8 +788,13 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
     if (a->shift_out && (!a->stat_out || a->ln_gamma)) return ser_fail(-19, "ser_gemm: shift_out needs stat_out and no fused-LN epilogue");
     if (a->mean_out && !a->ln_stats_in) return ser_fail(-20, "ser_gemm: mean_out needs ln_stats_in");
-    if (a->out_mode && a->out_mode != a->mode && !(a->mode == SER_MODE_FP32X && a->out_mode == SER_MODE_FP16 && !a->ln_gamma))
-        return ser_fail(-21, "ser_gemm: out_mode %d with mode %d (only FP32X -> FP16 without the LayerNorm epilogue converts)", a->out_mode, a->mode);
+    if (a->out_mode && a->out_mode != a->mode && !a->ln_gamma &&
+        !((a->mode == SER_MODE_FP32X && a->out_mode == SER_MODE_FP16) || (a->mode == SER_MODE_FP16 && a->out_mode == SER_MODE_FP16X) ||
+          (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16)))
+        return ser_fail(-21, "ser_gemm: out_mode %d with mode %d (FP32X -> FP16, FP16 <-> FP16X convert)", a->out_mode, a->mode);
+    if (a->out_mode && a->out_mode != a->mode && a->ln_gamma)
+        return ser_fail(-21, "ser_gemm: out_mode %d with the LayerNorm epilogue", a->out_mode);
+    if (a->mode == SER_MODE_FP16X && a->ln_gamma) return ser_fail(-22, "ser_gemm: the LayerNorm epilogue has no FP16X form");
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
     if ((a->ldo_act % 8) || (a->c_group_stride % 8)) return ser_fail(-18, "ser_gemm: act pitch / group stride must be multiples of 8");
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
@@ -788,13 +809,13 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         }
     }
 #endif
-    if (a->mode == SER_MODE_FP32X) {
+    if (a->mode == SER_MODE_FP32X || a->mode == SER_MODE_FP16X) {
         // both planes share a stage: the ring doubles, so FP32X uses the two configurations that still fit 160 KiB
         if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true, true>(a, s);
         // grouped positional conv (<= 64 output channels per group): 128x64 tiles of 32x64 wave tiles, like the bf16 path's -- the
         // 128x128 tile below computes 64 dead columns per group (fp32x pos-conv: 360 us against 100 us in bf16)
         static const int x32_n64 = [] { const char* e = getenv("SER_GEMM_N64"); return e ? atoi(e) : 1; }();
-        if (x32_n64 && a->N <= 64) return launch_cfg<4, 1, 2, 4, 32, 2, false, true>(a, s);
+        if (x32_n64 && a->N <= 64 && a->mode == SER_MODE_FP32X) return launch_cfg<4, 1, 2, 4, 32, 2, false, true>(a, s);
         // Large grids: 256x128 tiles of 64x64 wave tiles on a 32-deep, 3-stage ring (144 KiB): 16 fragments feed 48 MFMAs per
         // k-step (0.33 LDS fragment reads per MFMA against 0.5 for the 32x64 wave tile below), one ping-pong phase per K tile
         static const long x32_256_min = [] { const char* e = getenv("SER_GEMM_X32_256_MIN"); return e ? atol(e) : 100L; }();   // 100: M = 3992 out-proj / FC2 (128 tiles) gain, M = 1996 ones (64 tiles) lose

@@ -317,6 +317,9 @@ extern "C" int ser_layernorm(const float* x, int64_t ldx, const float* g, const 
     else if (mode == SER_MODE_FP16)
         hipLaunchKernelGGL(layernorm_kernel<SER_MODE_FP16>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
                            out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
+                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
     else return ser_fail(-4, "ser_layernorm: bad mode %d", mode);
     return ser_check_launch("ser_layernorm");
 }
@@ -377,6 +380,9 @@ extern "C" int ser_row_center(const float* x, int64_t ldx, void* out_act, int64_
                            (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
     else if (mode == SER_MODE_FP16)
         hipLaunchKernelGGL(row_center_kernel<SER_MODE_FP16>, grid, block, 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(row_center_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, ldx,
                            (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
     else return ser_fail(-4, "ser_row_center: bad mode %d", mode);
     return ser_check_launch("ser_row_center");
@@ -570,6 +576,13 @@ __global__ void split_kernel(const float* __restrict__ x, unsigned short* __rest
             o[i] = (unsigned short)(pack_h2(x[i], 0.f) & 0xffffu);
             continue;
         }
+        if (mode == SER_MODE_FP16X) {
+            unsigned short h, l;
+            split_h(x[i], h, l);
+            o[i] = h;
+            o[plane + i] = l;
+            continue;
+        }
         unsigned short h, l;
         split_bf(x[i], h, l);
         o[i] = h;
@@ -603,6 +616,7 @@ extern "C" int ser_ragged_index(const int32_t* row_offs, const int64_t* base, in
 
 extern "C" int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, int64_t n, void* stream) {
     if (!x || !out || n <= 0) return ser_fail(-1, "ser_split_bf16: bad arguments");
+    if (mode < SER_MODE_BF16 || mode > SER_MODE_FP16X) return ser_fail(-2, "ser_split_bf16: bad mode %d", mode);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,

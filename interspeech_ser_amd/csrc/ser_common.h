@@ -40,22 +40,40 @@ __device__ __forceinline__ unsigned int pack_h2(float a, float b) {
 __device__ __forceinline__ float h2f(unsigned short h) {
     return (float)__builtin_bit_cast(_Float16, h);
 }
+// element format / plane count of a numerics mode's operand tensors
+template <int MODE> struct mode_traits {
+    static constexpr bool f16 = (MODE == SER_MODE_FP16 || MODE == SER_MODE_FP16X || MODE == SER_MODE_FP16Q);      // IEEE fp16 elements (else bf16)
+    static constexpr int planes = (MODE == SER_MODE_FP32X || MODE == SER_MODE_FP16X || MODE == SER_MODE_FP16Q) ? 2 : 1;   // FP16Q (ser_attention): of q, k
+};
 // one 16-bit operand element -> fp32, in the format of MODE's planes
 template <int MODE>
 __device__ __forceinline__ float elem2f(unsigned short h) {
-    if (MODE == SER_MODE_FP16) return h2f(h);
+    if (mode_traits<MODE>::f16) return h2f(h);
     return bf2f(h);
 }
 // two fp32 -> one packed pair of MODE's 16-bit operand format (single-plane modes)
 template <int MODE>
 __device__ __forceinline__ unsigned int pack2(float a, float b) {
-    if (MODE == SER_MODE_FP16) return pack_h2(a, b);
+    if (mode_traits<MODE>::f16) return pack_h2(a, b);
     return pack_bf2(a, b);
 }
 // x ~= hi + lo with both halves bf16: 16 significand bits survive.
 __device__ __forceinline__ void split_bf(float x, unsigned short& hi, unsigned short& lo) {
     hi = f2bf(x);
     lo = f2bf(x - bf2f(hi));
+}
+// x ~= hi + lo with both halves fp16 (SER_MODE_FP16X): 22 significand bits survive while lo stays a normal fp16 number
+// (|x| >= 2^-3); below that lo is an fp16 subnormal and the pair keeps an ABSOLUTE error of 2^-25 -- the MFMA keeps fp16
+// subnormal operands (tools/f16_denorm_probe.py).  hi is the plain fp16 copy, so single-product FP16 launches read it as is.
+__device__ __forceinline__ void split_h(float x, unsigned short& hi, unsigned short& lo) {
+    hi = (unsigned short)(pack_h2(x, 0.f) & 0xffffu);
+    lo = (unsigned short)(pack_h2(x - h2f(hi), 0.f) & 0xffffu);
+}
+// two-plane split in MODE's element format
+template <int MODE>
+__device__ __forceinline__ void split2(float x, unsigned short& hi, unsigned short& lo) {
+    if (mode_traits<MODE>::f16) split_h(x, hi, lo);
+    else split_bf(x, hi, lo);
 }
 // erf by a clamped odd rational minimax x*P(x^2)/Q(x^2) on [-4, 4] (|err| < 5e-7, branch-free,
 // 11 FMA + v_rcp_f32): the GEMM epilogues apply GELU to 30M+ elements per launch, where the
@@ -135,13 +153,13 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
 // One MFMA step on 8 + 8 operand elements per lane in MODE's 16-bit format (same lane maps for bf16 and f16).
 template <int MODE>
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    if (MODE == SER_MODE_FP16)
+    if (mode_traits<MODE>::f16)
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 template <int MODE>
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    if (MODE == SER_MODE_FP16)
+    if (mode_traits<MODE>::f16)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -161,12 +179,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // pointer `dst` (8-byte aligned).  `plane` = element distance to the lo plane.
 template <int MODE>
 __device__ __forceinline__ void store_act4(unsigned short* dst, int64_t plane, float a, float b, float c, float d) {
-    if (MODE != SER_MODE_FP32X) {
+    if (mode_traits<MODE>::planes == 1) {
         u32x2 v = {pack2<MODE>(a, b), pack2<MODE>(c, d)};
         *(u32x2*)dst = v;
     } else {
         unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-        split_bf(a, h0, l0); split_bf(b, h1, l1); split_bf(c, h2, l2); split_bf(d, h3, l3);
+        split2<MODE>(a, h0, l0); split2<MODE>(b, h1, l1); split2<MODE>(c, h2, l2); split2<MODE>(d, h3, l3);
         u32x2 vh = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
         u32x2 vl = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
         *(u32x2*)dst = vh;
@@ -178,13 +196,13 @@ __device__ __forceinline__ void store_act4(unsigned short* dst, int64_t plane, f
 // instructions of two store_act4 -- epilogue store tails are issue-bound, not bandwidth-bound.
 template <int MODE>
 __device__ __forceinline__ void store_act8(unsigned short* dst, int64_t plane, const float (&v)[8]) {
-    if (MODE != SER_MODE_FP32X) {
+    if (mode_traits<MODE>::planes == 1) {
         u32x4 o = {pack2<MODE>(v[0], v[1]), pack2<MODE>(v[2], v[3]), pack2<MODE>(v[4], v[5]), pack2<MODE>(v[6], v[7])};
         *(u32x4*)dst = o;
     } else {
         unsigned short h[8], l[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) split_bf(v[i], h[i], l[i]);
+        for (int i = 0; i < 8; ++i) split2<MODE>(v[i], h[i], l[i]);
         u32x4 oh, ol;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -204,14 +222,14 @@ __device__ __forceinline__ void store_act8(unsigned short* dst, int64_t plane, c
 // dst already points at this lane's 8-column run; every lane of the pair must call (ok only gates the store).
 template <int MODE>
 __device__ __forceinline__ void store_act8_swap(unsigned short* dst, int64_t plane, bool ok, const float (&v)[8]) {
-    if (MODE != SER_MODE_FP32X) {
+    if (mode_traits<MODE>::planes == 1) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(pack2<MODE>(v[0], v[1]), pack2<MODE>(v[4], v[5]), false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(pack2<MODE>(v[2], v[3]), pack2<MODE>(v[6], v[7]), false, false);
         if (ok) *(u32x4*)dst = (u32x4){s0[0], s1[0], s0[1], s1[1]};
     } else {
         unsigned short h[8], l[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) split_bf(v[i], h[i], l[i]);
+        for (int i = 0; i < 8; ++i) split2<MODE>(v[i], h[i], l[i]);
         unsigned ph[4], pl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -233,11 +251,19 @@ __device__ __forceinline__ void store_act8_swap(unsigned short* dst, int64_t pla
 template <int MODE>
 __device__ __forceinline__ void load_act8(const unsigned short* src, int64_t plane, float (&v)[8]) {
     u32x4 h = *(const u32x4*)src;
-    if (MODE == SER_MODE_FP16) {
+    if (mode_traits<MODE>::f16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[2 * i] = h2f((unsigned short)(h[i] & 0xffffu));
             v[2 * i + 1] = h2f((unsigned short)(h[i] >> 16));
+        }
+        if (MODE == SER_MODE_FP16X) {
+            const u32x4 l = *(const u32x4*)(src + plane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] += h2f((unsigned short)(l[i] & 0xffffu));
+                v[2 * i + 1] += h2f((unsigned short)(l[i] >> 16));
+            }
         }
         return;
     }

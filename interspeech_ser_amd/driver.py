@@ -47,9 +47,11 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
     p.add_argument("--use_average", type=str, default="n")
     # additive
     p.add_argument("--batch_size", type=int, default=16)
-    p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "f16", "bf16"],
-                   help="fp32x: fp32-grade results (~2e-5 of the fp32 reference); f16: fp32x conv stem + fp16 encoder "
-                        "layers (within the 1e-3 parity gate, ~2x faster); bf16: fastest (~1e-2).  Limits: WavLM utterances up "
+    p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "f16a", "f16q", "f16", "bf16"],
+                   help="fp32x: fp32-grade results everywhere (~2e-5 of the fp32 reference); f16a: fp32-grade conv stem and "
+                        "attention blocks, single-product fp16 feed-forward (within 1e-3 on every stress fixture); f16q: only the "
+                        "attention-logit path (q / k projection, QK^T) fp32-grade; f16: fp16 layers throughout (within 1e-3 on "
+                        "Gaussian weights, 3-5e-3 under sharp attention); bf16: fastest (~1e-2).  Limits: WavLM utterances up "
                         "to ~2 min (the relative-position bias window of one utterance must fit the 160 KiB LDS; longer "
                         "files are reported per file and skipped), utterances of at least 400 samples")
     p.add_argument("--checkpoint", type=str, default="",

@@ -29,11 +29,20 @@ from . import _lib
 from ._lib import GemmArgs, check, lib
 from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
-MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16}
+MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16}
 # "f16": encoder layers on single-product fp16 operands (11 significand bits at the bf16 MFMA rate), the convolutional
 # stem -- where operand rounding hurts most and only 13 % of the FLOPs live -- on the 3-product FP32X split.
-_PLANES = {_lib.MODE_BF16: 1, _lib.MODE_FP32X: 2, _lib.MODE_FP16: 1}
-_DTYPE = {_lib.MODE_BF16: torch.bfloat16, _lib.MODE_FP32X: torch.bfloat16, _lib.MODE_FP16: torch.float16}
+# "f16q": "f16" with the LOGIT path of every layer fp32-grade: the q / k (+ WavLM gate) columns of the packed projection and
+# S = K Q^T inside the attention kernel run the 3-product split on fp16 hi + lo planes (SER_MODE_FP16X), v / P V / output
+# projection / feed-forward stay single-product fp16.  A softmax weight moves by (logit error) * ln 2, so q / k rounding is
+# what sharp attention maps (trained checkpoints, LoRA-scaled query projections) amplify; ~19 % of the layer FLOPs pay 3x.
+# "f16a": the whole ATTENTION BLOCK of every layer (packed projection, attention, output projection) on the fp16 hi + lo split,
+# the feed-forward pair (62 % of the layer FLOPs) on single fp16 products.  tools/numerics_whatif.py: under sharp attention the
+# error comes from the attention block as a whole -- rounding v, P, the context rows or the output-projection weights once is
+# amplified by the following layers' softmax as much as rounding q and k -- while the feed-forward rounding is benign.
+_PLANES = {_lib.MODE_BF16: 1, _lib.MODE_FP32X: 2, _lib.MODE_FP16: 1, _lib.MODE_FP16X: 2}
+_DTYPE = {_lib.MODE_BF16: torch.bfloat16, _lib.MODE_FP32X: torch.bfloat16, _lib.MODE_FP16: torch.float16,
+          _lib.MODE_FP16X: torch.float16}
 
 
 # A/B knob (tools/): SER_NO_SHIFT=1 turns the shifted operand copy of the encoder layers off (state 0 is still centred)
@@ -167,7 +176,10 @@ class _EncoderBase:
         self.device = torch.device(device)
         self.mode_name = mode
         self.mode = MODES[mode]                                   # encoder layers
-        self.stem_mode = _lib.MODE_FP32X if mode == "f16" else self.mode      # conv stem (+ projection, positional conv)
+        self.stem_mode = _lib.MODE_FP32X if mode in ("f16", "f16q", "f16a") else self.mode      # conv stem (+ projection, positional conv)
+        self.qk_mode = _lib.MODE_FP16X if mode == "f16q" else None             # logit path on its own launch (None: one packed launch)
+        self.attn_mode = _lib.MODE_FP16X if mode == "f16a" else self.mode      # packed projection, context rows, output projection
+        self.x_mode = self.qk_mode or self.attn_mode                           # format of the operand copy the packed projection reads
         self.planes, self.stem_planes = _PLANES[self.mode], _PLANES[self.stem_mode]
         self._cache: Dict = {}
         # when a list, every ser_gemm launch appends (start_event, end_event, algorithmic_flops):
@@ -187,23 +199,25 @@ class _EncoderBase:
     def _dev_f32(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(torch.float32).contiguous().to(self.device)
 
-    def _linear(self, w: torch.Tensor, b: Optional[torch.Tensor], stem: bool = False) -> Linear:
-        """fp32 [N, K] -> 16-bit operand planes on the device (ser_split_bf16): bf16 hi (+ lo), or fp16."""
+    def _linear(self, w: torch.Tensor, b: Optional[torch.Tensor], stem: bool = False, mode: Optional[int] = None) -> Linear:
+        """fp32 [N, K] -> 16-bit operand planes on the device (ser_split_bf16): bf16 hi (+ lo), or fp16 (hi + lo for FP16X)."""
         w = w.detach().to(torch.float32).contiguous()
         N, K = w.shape
         src = w.to(self.device)
-        mode = self.stem_mode if stem else self.mode
+        if mode is None:
+            mode = self.stem_mode if stem else self.mode
         out = torch.empty((_PLANES[mode], N, K), dtype=_DTYPE[mode], device=self.device)
         check(lib.ser_split_bf16(src.data_ptr(), out.data_ptr(), N * K, mode, N * K, _stream()), "ser_split_bf16")
         torch.cuda.current_stream().synchronize()
         return Linear(out, None if b is None else self._dev_f32(b), N, K)
 
-    def _linear_ln(self, w: torch.Tensor, b: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor) -> Linear:
+    def _linear_ln(self, w: torch.Tensor, b: Optional[torch.Tensor], ln_w: torch.Tensor, ln_b: torch.Tensor,
+                   mode: Optional[int] = None) -> Linear:
         """Linear that consumes LayerNorm(x) given the RAW x (deferred LayerNorm, ser_hip.h):
         store W' = W * gamma, colsum(W') of exactly the bf16 planes the MFMAs will read, and
         t = beta W^T + b.  Load-time transform, like the weight-norm fold."""
         w64, g64, be64 = w.detach().double(), ln_w.detach().double(), ln_b.detach().double()
-        lin = self._linear((w64 * g64[None, :]).float(), None)
+        lin = self._linear((w64 * g64[None, :]).float(), None, mode=mode)
         t = w64 @ be64
         if b is not None:
             t = t + b.detach().double()
@@ -211,8 +225,9 @@ class _EncoderBase:
         lin.colsum = lin.w.double().sum(dim=(0, 2)).float().contiguous()
         return lin
 
-    def _new_act(self, rows, cols, zero=False, extra_rows=0, stem=False) -> Act:
-        mode = self.stem_mode if stem else self.mode
+    def _new_act(self, rows, cols, zero=False, extra_rows=0, stem=False, mode: Optional[int] = None) -> Act:
+        if mode is None:
+            mode = self.stem_mode if stem else self.mode
         return Act(rows, cols, _PLANES[mode], self.device, zero=zero, extra_rows=extra_rows, dtype=_DTYPE[mode])
 
     # ------------------------------------------------------------------ launchers
@@ -221,7 +236,7 @@ class _EncoderBase:
               residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
               out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0,
               ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0,
-              col_scale=1.0, col_scale_end=0, shift=None, ln_mean=None, stem=False, out_mode=0):
+              col_scale=1.0, col_scale_end=0, shift=None, ln_mean=None, stem=False, out_mode=0, mode=None, out_col=0):
         rec = self._rec
         g = rec.slot("gemm") if rec is not None else GemmArgs()
         g.A = a.ptr + a_ptr_offset
@@ -234,7 +249,7 @@ class _EncoderBase:
         g.M, g.N, g.K = M, (lin.N if N is None else N), (lin.K if K is None else K)
         g.groups = groups
         g.a_group_stride, g.w_group_stride, g.c_group_stride = a_group_stride, w_group_stride, c_group_stride
-        g.mode = self.stem_mode if stem else self.mode
+        g.mode = mode if mode is not None else (self.stem_mode if stem else self.mode)
         g.out_mode = out_mode if out_mode != g.mode else 0
         g.bias = _ptr(lin.b)
         g.act = act
@@ -243,7 +258,7 @@ class _EncoderBase:
         g.res_row_mod = res_row_mod
         g.out_f32 = _ptr(out_f32)
         g.ldo_f32 = ldo_f32
-        g.out_act = None if out_act is None else out_act.ptr
+        g.out_act = None if out_act is None else out_act.ptr + 2 * out_col     # out_col: first column written (16-bit elements)
         g.ldo_act = 0 if out_act is None else out_act.cols
         g.out_plane_stride = 0 if out_act is None else out_act.plane_stride
         g.out_rowmap = _ptr(out_rowmap)
@@ -275,7 +290,7 @@ class _EncoderBase:
         # algorithmic FLOPs: 2*M*N*K over real (unpadded) channels, no tile-padding FLOPs
         k_real = g.K if k_algo is None else k_algo
         # algorithmic HBM bytes: every operand / result element touched exactly once
-        planes = self.stem_planes if stem else self.planes
+        planes = _PLANES[g.mode]
         nbytes = 2.0 * planes * (M * k_real * groups + g.N * groups * k_real)
         nbytes += 4.0 * M * g.N * groups * ((residual is not None) + (out_f32 is not None))
         nbytes += 2.0 * planes * M * g.N * groups * (out_act is not None)
@@ -308,33 +323,63 @@ class _EncoderBase:
         if rec is not None:
             a = rec.slot("row_center")
             a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride = x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride
-            a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.mode, rows, D
+            a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.x_mode, rows, D
             rec.commit(_lib.OP_ROW_CENTER, a, rows=rows)
             return
         check(lib.ser_row_center(x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride, stats.data_ptr(), groups,
-                                 shift.data_ptr(), self.mode, rows, D, self._s()), "ser_row_center")
+                                 shift.data_ptr(), self.x_mode, rows, D, self._s()), "ser_row_center")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
                    gru_const=None, key_lens=None, bias2d=None):
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
+        # column blocks of the packed projection: [q | k | v | gate] or, with the logit path on its own launch ("f16q"), [q | k | gate | v]
+        q_col, k_col, v_col, gate_col = self._qkv_cols()
+        amode = _lib.MODE_FP16Q if self.qk_mode is not None else self.attn_mode
         rec = self._rec
         if rec is not None:
             a = rec.slot("attention")
             a.qkv, a.ld, a.plane_stride = qkv.ptr, qkv.cols, qkv.plane_stride
-            a.q_col, a.k_col, a.v_col, a.B = 0, D, 2 * D, B
+            a.q_col, a.k_col, a.v_col, a.B = q_col, k_col, v_col, B
             a.frame_offs, a.table, a.gate = frame_offs_dev.data_ptr(), _ptr(table), _ptr(gate)
             a.max_frames, a.table_T = max_frames, table_T
             a.out, a.ldo, a.out_plane_stride = out.ptr, out.cols, out.plane_stride
-            a.H, a.dh, a.scale, a.mode, a.gate_col = H, dh, -1.0, self.mode, 3 * D        # q is pre-scaled
+            a.H, a.dh, a.scale, a.mode, a.gate_col = H, dh, -1.0, amode, gate_col       # q is pre-scaled
             a.gru_const, a.key_lens = _ptr(gru_const), _ptr(key_lens)
             a.bias2d, a.bias2d_ld = _ptr(bias2d), (0 if bias2d is None else bias2d.shape[-1])
             rec.commit(_lib.OP_ATTENTION, a, B=B, max_frames=max_frames, table_T=table_T)
             return
-        check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, 0, D, 2 * D, frame_offs_dev.data_ptr(), B,
+        check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, q_col, k_col, v_col, frame_offs_dev.data_ptr(), B,
                                 max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
-                                H, dh, -1.0, self.mode, 3 * D, _ptr(gru_const), _ptr(key_lens), _ptr(bias2d),
+                                H, dh, -1.0, amode, gate_col, _ptr(gru_const), _ptr(key_lens), _ptr(bias2d),
                                 0 if bias2d is None else bias2d.shape[-1], self._s()),   # q is pre-scaled
               "ser_attention")
+
+    def _gate_pad(self) -> int:
+        """extra columns of the packed projection: the WavLM gate's two pre-activations per head, padded to a multiple of 8"""
+        return ((2 * self.geo.heads + 7) // 8) * 8 if self.geo.family == FAMILY_WAVLM else 0
+
+    def _qkv_cols(self):
+        """(q, k, v, gate) first columns inside the packed projection output"""
+        D = self.geo.hidden
+        if self.qk_mode is None:
+            return 0, D, 2 * D, 3 * D
+        return 0, D, 2 * D + self._gate_pad(), 2 * D
+
+    def _qkv_gemm(self, pl, lay, M: int, first: bool, gx: int, ln_mean) -> None:
+        """packed Q K V (+ gate) projection with LayerNorm 1 deferred into it; q leaves multiplied by dh^-0.5 * log2(e).
+        "f16q": two launches over the same operand copy -- [q | k | gate] as the 3-product FP16X GEMM on both planes of x,
+        [v] as a single-product FP16 GEMM on its hi plane."""
+        geo = self.geo
+        D = geo.hidden
+        stats = pl["px0"] if first else pl["px"]
+        scale = geo.head_dim ** -0.5 * 1.4426950408889634
+        if self.qk_mode is None:
+            self._gemm(pl["xa"], lay["qkv"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
+                       col_scale_end=D, ln_mean=ln_mean, mode=self.attn_mode)
+            return
+        self._gemm(pl["xa"], lay["qk"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
+                   col_scale_end=D, ln_mean=ln_mean, mode=self.qk_mode)
+        self._gemm(pl["xa"], lay["v"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], out_col=self._qkv_cols()[2])
 
     @staticmethod
     def _stat_groups(n_cols: int, groups: int = 1) -> int:
@@ -364,17 +409,14 @@ class _EncoderBase:
             if self.block_trace is not None:
                 b0 = torch.cuda.Event(enable_timing=True)
                 b0.record()
-            # q columns leave the projection already multiplied by dh^-0.5 * log2(e)
-            self._gemm(pl["xa"], lay["qkv"], M, ln_stats=(pl["px0"] if i == 0 else pl["px"]), ln_groups=gx,
-                       out_act=pl["qkv"], col_scale=geo.head_dim ** -0.5 * 1.4426950408889634, col_scale_end=D,
-                       ln_mean=(pl["sx"], pl["mx"]) if shifted else None)
+            self._qkv_gemm(pl, lay, M, i == 0, gx, (pl["sx"], pl["mx"]) if shifted else None)
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"],
                                 table_T=pl["Tmax"], gru_const=lay["gate_c"])
             else:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
             self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D,
-                       out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD,
+                       out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD, mode=self.attn_mode, out_mode=self.mode,
                        shift=(pl["mx"], pl["sh"], lay["out_bias_mean"]) if shifted else None)
             if self.block_trace is not None:
                 b1 = torch.cuda.Event(enable_timing=True)
@@ -386,7 +428,7 @@ class _EncoderBase:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
             else:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D,
-                           out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD,
+                           out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD, out_mode=self.x_mode,
                            shift=(pl["mh"], pl["sx"], lay["fc2_bias_mean"]) if shifted else None)
             gx = gD
         self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
@@ -403,15 +445,15 @@ class _EncoderBase:
         wavlm = geo.family == FAMILY_WAVLM
         gD = self._stat_groups(D)
         for i, lay in enumerate(self.layers):
-            self._gemm(pl["xa"], lay["qkv"], M, ln_stats=(pl["px0"] if i == 0 else pl["px"]), ln_groups=(pl["first_groups"] if i == 0 else gD),
-                       out_act=pl["qkv"], col_scale=geo.head_dim ** -0.5 * 1.4426950408889634, col_scale_end=D, ln_mean=(pl["sx"], pl["mx"]))
+            self._qkv_gemm(pl, lay, M, i == 0, pl["first_groups"] if i == 0 else gD, (pl["sx"], pl["mx"]))
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"], table_T=pl["Tmax"],
                                 gru_const=lay["gate_c"])
             else:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
             self._gemm(pl["ctx"], lay["out"], M, residual=pl["h"], ldr=D, out_f32=pl["h"], ldo_f32=D, out_act=pl["ha"],
-                       stat_out=pl["ph"], stat_groups=gD, shift=(pl["mx"], pl["sh"], lay["out_bias_mean"]))
+                       stat_out=pl["ph"], stat_groups=gD, shift=(pl["mx"], pl["sh"], lay["out_bias_mean"]),
+                       mode=self.attn_mode, out_mode=self.mode)
         return len(self.layers)
 
     def _layer_weights(self, sd, p: str, a: str, ln1: str, ln2: str, fc1: str, fc2: str, k_bias: bool, gate: bool):
@@ -435,8 +477,14 @@ class _EncoderBase:
             ws.append(torch.cat([wg, torch.zeros(pad, D, device=wdev)], 0))
             bs.append(torch.cat([torch.stack([b8[:4].sum(), b8[4:].sum()]).repeat(H), torch.zeros(pad, device=wdev)]))
             lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
-        lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"])
-        lay["out"] = self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"])
+        if self.qk_mode is None:
+            lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=self.attn_mode)
+        else:
+            # logit path [q | k | gate] on fp16 hi + lo planes (3 products), [v] on one fp16 plane
+            lay["qk"] = self._linear_ln(torch.cat(ws[:2] + ws[3:], 0), torch.cat(bs[:2] + bs[3:], 0), sd[ln1 + ".weight"],
+                                        sd[ln1 + ".bias"], mode=self.qk_mode)
+            lay["v"] = self._linear_ln(ws[2], bs[2], sd[ln1 + ".weight"], sd[ln1 + ".bias"])
+        lay["out"] = self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"], mode=self.attn_mode)
         lay["fc1"] = self._linear_ln(sd[fc1 + ".weight"], sd[fc1 + ".bias"], sd[ln2 + ".weight"], sd[ln2 + ".bias"])
         lay["fc2"] = self._linear(sd[fc2 + ".weight"], sd[fc2 + ".bias"])
         # load-time part of the operand shift: a uniform offset in a bias moves the row mean by exactly its mean
@@ -447,9 +495,9 @@ class _EncoderBase:
     def _layer_buffers(self, pl, M: int, first_groups: int):
         geo, dev = self.geo, self.device
         D, Fd = geo.hidden, geo.ffn
-        nqkv = 3 * D + (((2 * geo.heads + 7) // 8) * 8 if geo.family == FAMILY_WAVLM else 0)
+        nqkv = 3 * D + self._gate_pad()
         gD = self._stat_groups(D)
-        pl["xa"] = self._new_act(M, D)
+        pl["xa"] = self._new_act(M, D, mode=self.x_mode)
         pl["ha"] = self._new_act(M, D)
         # row partial sums (sum, sum^2 per 64-column group).  One buffer per producer layout: a padding
         # slot (odd group count) is never written and must stay zero.
@@ -460,8 +508,8 @@ class _EncoderBase:
         pl["mh"] = torch.zeros(M, dtype=torch.float32, device=dev)       # absolute row mean of h (written by the FC1 GEMM)
         pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
         pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
-        pl["qkv"] = self._new_act(M, nqkv)
-        pl["ctx"] = self._new_act(M, D)
+        pl["qkv"] = self._new_act(M, nqkv, mode=self.x_mode)      # "f16q": q, k, gate columns carry a lo plane, v's stays unused
+        pl["ctx"] = self._new_act(M, D, mode=self.attn_mode)
         pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         pl["ffn"] = self._new_act(M, Fd)
         pl["last"] = torch.empty((M, D), dtype=torch.float32, device=dev)
@@ -573,7 +621,7 @@ class SpeechEncoder(_EncoderBase):
         # less than on the fp32x stem and, unlike the conv stack and the projection, moves the error by nothing measurable
         # (WavLM-large, K = 128 taps x 64 channels: 6.8e-4 either way; HuBERT-xlarge, 128 x 80: 8.0e-4 either way).  XLS-R-2B's
         # 128 x 120 = 15 360-long sums do feel fp16 operands (7.0e-4 -> 8.3e-4 at full geometry), so they stay on the stem format.
-        self.pos_in_stem = self.mode_name == "f16" and Cg * k > 128 * 80
+        self.pos_in_stem = self.mode_name in ("f16", "f16q", "f16a") and Cg * k > 128 * 80
         self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"], stem=self.pos_in_stem)
         self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
         self.layers = []
@@ -994,7 +1042,7 @@ class TextEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != FAMILY_ROBERTA:
             raise ValueError("TextEncoder needs a roberta geometry")
-        if mode == "f16":
+        if mode in ("f16", "f16q", "f16a"):
             raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
         sd = state_dict
         D = geo.hidden
@@ -1106,7 +1154,7 @@ class DebertaEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != "deberta":
             raise ValueError("DebertaEncoder needs a deberta geometry")
-        if mode == "f16":
+        if mode in ("f16", "f16q", "f16a"):
             raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
         if geo.head_dim != 64:
             raise ValueError("DeBERTa path: head dim must be 64 (K of the position GEMMs; deberta-v3 base/large have 64)")

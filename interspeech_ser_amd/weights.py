@@ -168,7 +168,8 @@ def apply_stress(sd: StateDict, geo: EncoderGeometry, kind: str) -> StateDict:
     * ``"rowmean"``: a uniform offset on every channel (positional-conv bias +40, which passes its GELU unchanged; each
       feed-forward output bias +3; one attention LayerNorm bias x8), so that rows have |mean| >> std: the one-pass
       variance and the deferred-LayerNorm term ``acc - mean * colsum`` of csrc/gemm.hip cancel catastrophically
-      unless the operands are stored shifted.
+      unless the operands are stored shifted;
+    * ``"sharp"``: q / k projections x4 (logits x16): near one-hot attention rows.
     """
     D = geo.hidden
     sd = {k: v.clone() for k, v in sd.items()}
@@ -188,6 +189,14 @@ def apply_stress(sd: StateDict, geo: EncoderGeometry, kind: str) -> StateDict:
         for i in range(geo.num_layers):
             sd[fc2.format(i) + ".bias"] += 3.0
         sd["encoder.layers.0.layer_norm.bias"] *= 8.0
+    elif kind == "sharp":
+        # sharp attention: query and key projections 4x larger -> logits 16x larger, softmax rows near one-hot -- what
+        # trained checkpoints (and LoRA-scaled query projections) have and Gaussian weights do not.  A softmax weight moves
+        # by (logit error) * ln 2, so this is the fixture that separates single-product q / k rounding from the fp32 reference.
+        for i in range(geo.num_layers):
+            for proj in ("q_proj", "k_proj"):
+                for leaf in ("weight", "bias"):
+                    sd[f"encoder.layers.{i}.attention.{proj}.{leaf}"] *= 4.0
     else:
         raise ValueError(f"unknown stress kind '{kind}'")
     return sd

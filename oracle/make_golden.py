@@ -281,6 +281,15 @@ def stress_cases():
     speech_case("tiny_hubert_outlier", C.TINY_HUBERT, 22, [16000, 9000], stress="outliers")
     speech_case("tiny_wavlm_rowmean", C.TINY_WAVLM, 23, [16000, 9000], stress="rowmean")
     speech_case("tiny_hubert_rowmean", C.TINY_HUBERT, 24, [16000, 9000], stress="rowmean")
+    sharp_cases()
+
+
+def sharp_cases():
+    """Sharp-attention fixtures (weights.apply_stress "sharp"): the envelope of the single-product numerics modes is set by the
+    attention logits, so the pin comes from the HF classes, not from an oracle-vs-oracle comparison."""
+    speech_case("tiny_wavlm_sharp", C.TINY_WAVLM, 25, [16000, 9000], stress="sharp")
+    speech_case("tiny_hubert_sharp", C.TINY_HUBERT, 26, [16000, 9000], stress="sharp")
+    speech_case("tiny_wav2vec2_sharp", C.TINY_WAV2VEC2, 27, [12000], stress="sharp")
 
 
 def main():
@@ -292,6 +301,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "deberta_conv":
         deberta_case("tiny_deberta_conv_d128h2", C.TINY_DEBERTA_CONV, 19)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sharp":         # sharp-attention fixtures only
+        sharp_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "stress":        # outlier-stress fixtures only
         stress_cases()
         return

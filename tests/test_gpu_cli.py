@@ -142,7 +142,8 @@ def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
     assert torch.isfinite(loss)
 
 
-@pytest.mark.parametrize("family,mode", [("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16")])
+@pytest.mark.parametrize("family,mode", [("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16a"), ("hubert", "f16a"),
+                                         ("wavlm", "f16q"), ("hubert", "f16q"), ("wavlm", "f16")])
 def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, capsys, family, mode):
     """Next row 8f-4 end to end (preprocessing/preprocess_speech_pretrained.py:108-177): a PEFT-wrapped checkpoint --
     ``wavlm.base_model.model.*`` names, ``q_proj`` / ``v_proj`` split into ``base_layer`` + ``lora_A`` / ``lora_B`` (r = 8,
@@ -201,11 +202,14 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
         worst = max(worst, float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))))
         changed = max(changed, float((plain - ref).abs().max()))
     assert changed > 0.1, changed            # the adapters matter ...
-    # ... and the merged HIP path equals the un-merged reference arithmetic.  fp32x: the parity gate.  f16: these adapters make
-    # the query projection ~4x larger than the base weights, i.e. attention logits ~4x larger, and single-product operand
-    # rounding (2^-12 relative per operand) moves a softmax weight by (logit error) * ln 2: measured 2.9e-3 here against
-    # 6-8e-4 on the unadapted geometries.  That envelope of the mode is stated in DESIGN.md section 4; fp32x stays the default.
-    assert worst < (1e-3 if mode == "fp32x" else 5e-3), worst
+    # ... and the merged HIP path equals the un-merged reference arithmetic.  fp32x and f16a: the parity gate (1e-3).  f16: these
+    # adapters make the query projection ~4x larger than the base weights, i.e. attention logits ~4x larger, and single-product
+    # operand rounding (2^-12 relative per operand) moves a softmax weight by (logit error) * ln 2: measured 2.9e-3 here against
+    # 6-8e-4 on the unadapted geometries.  f16q (fp32-grade logit path only) measures 1.8e-3 / 4.0e-3: roundings of v, P, the
+    # context rows and the output projection are amplified by the NEXT layer's softmax just the same (tools/numerics_whatif.py)
+    # -- the reason f16a (whole attention block on the 3-product split) exists.
+    print(f"LoRA {family} {mode}: worst rel err {worst:.3e}")
+    assert worst < (5e-3 if mode in ("f16", "f16q") else 1e-3), worst
 
 
 def test_whisper_lora_checkpoint_through_the_driver(tmp_path, capsys):
