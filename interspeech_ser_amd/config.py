@@ -178,6 +178,94 @@ def geometry_for(ssl_type: str) -> EncoderGeometry:
     raise OSError(f"No geometry registered for ssl_type '{ssl_type}'")
 
 
+def geometry_from_config(cfg: dict, name: str = "") -> EncoderGeometry:
+    """Geometry from a checkpoint's ``config.json`` -- what ``AutoModel.from_pretrained(--ssl_type)`` reads for ANY hub id or
+    local snapshot (preprocess_speech.py:111-112, preprocess_whisper.py:119-120), so fine-tunes published under another name
+    work without a registry entry.  Variants this build does not implement are refused with ``OSError``, the class the
+    reference's driver reports as "No pretrained model found" (:115-117): GroupNorm feature extractors
+    (``feat_extract_norm="group"``: wav2vec2-base, hubert-base / large-ll60k) and post-LayerNorm encoders
+    (``do_stable_layer_norm=False``)."""
+    mt = str(cfg.get("model_type", "")).lower()
+    name = name or str(cfg.get("_name_or_path", "")) or mt
+    if mt in (FAMILY_WAVLM, FAMILY_WAV2VEC2, FAMILY_HUBERT):
+        if cfg.get("feat_extract_norm", "group") != "layer":
+            raise OSError(f"{name}: feat_extract_norm='{cfg.get('feat_extract_norm', 'group')}' (GroupNorm over time) is not supported; "
+                          "the path implements the layer-norm feature extractor of the *-large / xlarge / XLS-R checkpoints")
+        if not cfg.get("do_stable_layer_norm", False):
+            raise OSError(f"{name}: do_stable_layer_norm=False (post-LayerNorm encoder) is not supported")
+        if mt == FAMILY_HUBERT and not cfg.get("feat_proj_layer_norm", True):
+            raise OSError(f"{name}: feat_proj_layer_norm=False is not supported")
+        conv_dim = tuple(int(c) for c in cfg.get("conv_dim", (512,) * 7))
+        return EncoderGeometry(
+            family=mt, num_layers=int(cfg["num_hidden_layers"]), hidden=int(cfg["hidden_size"]),
+            heads=int(cfg["num_attention_heads"]), ffn=int(cfg["intermediate_size"]), conv_dim=conv_dim,
+            conv_kernel=tuple(int(k) for k in cfg.get("conv_kernel", (10, 3, 3, 3, 3, 2, 2))),
+            conv_stride=tuple(int(k) for k in cfg.get("conv_stride", (5, 2, 2, 2, 2, 2, 2))),
+            conv_bias=bool(cfg.get("conv_bias", False)), feat_proj_layer_norm=bool(cfg.get("feat_proj_layer_norm", True)),
+            pos_conv_kernel=int(cfg.get("num_conv_pos_embeddings", 128)), pos_conv_groups=int(cfg.get("num_conv_pos_embedding_groups", 16)),
+            num_buckets=int(cfg.get("num_buckets", 320)), max_bucket_distance=int(cfg.get("max_bucket_distance", 800)),
+            layer_norm_eps=float(cfg.get("layer_norm_eps", 1e-5)), name=name)
+    if mt == FAMILY_WHISPER:
+        return EncoderGeometry(
+            family=FAMILY_WHISPER, num_layers=int(cfg["encoder_layers"]), hidden=int(cfg["d_model"]),
+            heads=int(cfg["encoder_attention_heads"]), ffn=int(cfg["encoder_ffn_dim"]), n_mels=int(cfg.get("num_mel_bins", 80)),
+            max_source_positions=int(cfg.get("max_source_positions", 1500)), name=name)
+    if mt in ("roberta", "xlm-roberta"):
+        return EncoderGeometry(
+            family=FAMILY_ROBERTA, num_layers=int(cfg["num_hidden_layers"]), hidden=int(cfg["hidden_size"]),
+            heads=int(cfg["num_attention_heads"]), ffn=int(cfg["intermediate_size"]), vocab_size=int(cfg["vocab_size"]),
+            max_positions=int(cfg.get("max_position_embeddings", 514)), pad_token_id=int(cfg.get("pad_token_id", 1)),
+            type_vocab_size=int(cfg.get("type_vocab_size", 1)), layer_norm_eps=float(cfg.get("layer_norm_eps", 1e-5)), name=name)
+    if mt == "deberta-v2":
+        pos_att = cfg.get("pos_att_type") or []
+        pos_att = pos_att.split("|") if isinstance(pos_att, str) else list(pos_att)
+        if not cfg.get("relative_attention", False) or sorted(pos_att) != ["c2p", "p2c"] or not cfg.get("share_att_key", False) \
+                or cfg.get("position_biased_input", True) or str(cfg.get("norm_rel_ebd", "none")) != "layer_norm":
+            raise OSError(f"{name}: only the deberta-v3 / v2-xlarge attention configuration is supported (relative_attention, "
+                          "pos_att_type p2c|c2p, share_att_key, norm_rel_ebd layer_norm, no absolute positions)")
+        return EncoderGeometry(
+            family=FAMILY_DEBERTA, num_layers=int(cfg["num_hidden_layers"]), hidden=int(cfg["hidden_size"]),
+            heads=int(cfg["num_attention_heads"]), ffn=int(cfg["intermediate_size"]), vocab_size=int(cfg["vocab_size"]),
+            max_positions=int(cfg.get("max_position_embeddings", 512)), pad_token_id=int(cfg.get("pad_token_id", 0)),
+            type_vocab_size=int(cfg.get("type_vocab_size", 0)), layer_norm_eps=float(cfg.get("layer_norm_eps", 1e-7)),
+            position_buckets=int(cfg.get("position_buckets", 256)), text_conv_kernel=int(cfg.get("conv_kernel_size", 0) or 0), name=name)
+    raise OSError(f"{name}: model_type '{mt}' is not an encoder this path implements "
+                  "(wavlm / wav2vec2 / hubert / whisper / roberta / deberta-v2)")
+
+
+def find_config_json(ssl_type: str, checkpoint: str = "") -> str:
+    """Path of the ``config.json`` that belongs to the weights the driver will load: next to ``--checkpoint`` (a snapshot
+    directory or a file inside one), else in the offline HF cache snapshot of ``--ssl_type``; "" when there is none."""
+    import os
+    cands = []
+    if checkpoint:
+        cands.append(os.path.join(checkpoint if os.path.isdir(checkpoint) else os.path.dirname(os.path.abspath(checkpoint)), "config.json"))
+    elif os.path.isdir(ssl_type):
+        cands.append(os.path.join(ssl_type, "config.json"))
+    home = os.environ.get("HF_HOME", os.path.join(os.path.expanduser("~"), ".cache", "huggingface"))
+    snap = os.path.join(home, "hub", "models--" + ssl_type.replace("/", "--"), "snapshots")
+    if not checkpoint and os.path.isdir(snap):
+        cands += [os.path.join(snap, rev, "config.json") for rev in sorted(os.listdir(snap))]
+    for c in cands:
+        if os.path.isfile(c):
+            return c
+    return ""
+
+
+def resolve_geometry(ssl_type: str, checkpoint: str = "") -> EncoderGeometry:
+    """``config.json`` of the checkpoint when there is one (any name), else the built-in table by ``--ssl_type``."""
+    import json
+    path = find_config_json(ssl_type, checkpoint)
+    if path:
+        try:
+            with open(path, "r") as f:
+                cfg = json.load(f)
+        except (OSError, ValueError) as e:
+            raise OSError(f"cannot read {path}: {e}")
+        return geometry_from_config(cfg, name=ssl_type)
+    return geometry_for(ssl_type)
+
+
 def with_layers(geo: EncoderGeometry, layers: int) -> EncoderGeometry:
     return replace(geo, num_layers=layers)
 

@@ -205,6 +205,8 @@ extern "C" int ser_pt_write_f32(const char* path, const float* host_data, int64_
     std::string stem(path);
     const size_t slash = stem.find_last_of('/');
     if (slash != std::string::npos) stem = stem.substr(slash + 1);
+    // the host writes "<name>.pt.tmp" and renames it when complete (frontend.save_feature): the archive is <name>.pt's
+    if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".tmp") == 0) stem.resize(stem.size() - 4);
     const size_t dot = stem.find_last_of('.');
     if (dot != std::string::npos && dot > 0) stem = stem.substr(0, dot);
     if (stem.empty()) stem = "archive";

@@ -25,9 +25,11 @@ def env() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int, int]:
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None, force: bool = False) -> Tuple[int, int, int]:
+    """``force``: create the process group even for a single rank (tests/test_gpu_dist.py runs every collective of this file on
+    the RCCL backend with world size 1 -- one GPU cannot host two RCCL ranks)."""
     rank, world, local_rank = env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -71,18 +73,27 @@ def broadcast_state_dict(sd: Optional[StateDict], src: int = 0) -> Tuple[StateDi
     Returns (state dict of fp32 tensors, seconds spent in the broadcast, bytes).  The tensors are VIEWS of the one
     flat bucket that was broadcast and stay where the collective left them -- in HBM on the "nccl" (RCCL) backend,
     on every rank including ``src`` -- so the weights cross xGMI once and never bounce through host memory; the
-    encoder constructors fold / split them on the device."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    encoder constructors fold / split them on the device and keep COPIES of the small fp32 vectors (engine._dev_f32), so
+    dropping the returned dict after ``build_encoder`` frees the bucket: weight memory is 1x, not fp32 + 16-bit planes."""
+    if not dist.is_initialized():
         assert sd is not None
         return sd, 0.0, 0
     rank = dist.get_rank()
     manifest = [[(k, tuple(sd[k].shape)) for k in sorted(sd)]] if rank == src else [None]
     dist.broadcast_object_list(manifest, src=src)
     entries = manifest[0]
-    total = sum(int(torch.Size(s).numel()) for _, s in entries)
+    # every entry starts on a 16-byte boundary of the bucket (the kernels read biases / LayerNorm vectors with 16-byte loads
+    # and the encoder constructors may pass a view straight to a launcher)
+    starts, total = [], 0
+    for _, shape in entries:
+        starts.append(total)
+        total += (int(torch.Size(shape).numel()) + 3) // 4 * 4
     dev = _comm_device()
     if rank == src:
-        flat = torch.cat([sd[k].reshape(-1).to(torch.float32) for k, _ in entries]).to(dev)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)      # filled tensor by tensor: no second host copy of the checkpoint
+        for (k, shape), o in zip(entries, starts):
+            n = int(torch.Size(shape).numel())
+            flat[o:o + n].copy_(sd[k].reshape(-1).to(torch.float32), non_blocking=False)
     else:
         flat = torch.empty(total, dtype=torch.float32, device=dev)
     if dev.type == "cuda":
@@ -96,11 +107,9 @@ def broadcast_state_dict(sd: Optional[StateDict], src: int = 0) -> Tuple[StateDi
     if rank == src and dev.type == "cpu":
         return sd, dt, total * 4                   # gloo: rank src already holds CPU tensors
     out: StateDict = {}
-    o = 0
-    for k, shape in entries:
+    for (k, shape), o in zip(entries, starts):
         n = int(torch.Size(shape).numel())
-        out[k] = flat[o:o + n].view(shape)         # no copy: a view into the bucket
-        o += n
+        out[k] = flat[o:o + n].view(shape)         # no copy: a view into the bucket, which lives until the last view is dropped
     return out, dt, total * 4
 
 

@@ -9,15 +9,16 @@ batches, each batch is one packed forward on the GPU through libserhip, decode
 and ``torch.save`` run in ``--num_workers`` host threads around it, and with
 ``torchrun`` the file list is sharded over ranks (one process per GPU).
 
-Deliberate, documented differences:
-* ``--n_layer`` is honoured by BOTH drivers (default -1 = last state).  The reference's
-  speech script parses it but then indexes ``hidden_states[N]`` with N = the number of
-  files already in ``--save_path`` at start-up (preprocess_speech.py:41,67), i.e. layer 0
-  on a fresh directory and a different layer on every re-run.  ``--compat_layer_quirk``
-  reproduces exactly that rule (N is taken once, on rank 0, before any rank writes).
-* additive flags: ``--batch_size``, ``--mode``, ``--checkpoint``, ``--synthetic_weights``,
-  ``--skip_existing``, ``--compat_layer_quirk``.  ``--seed`` (parsed and unused by the
-  reference) seeds the synthetic weights.
+Layer selection is the reference's (a19):
+* speech script: ``--n_layer`` is parsed and NOT used; the state written is ``hidden_states[N]`` with N = the number of
+  files found in ``--save_path`` at start-up (preprocess_speech.py:41,67) -- hidden_states[0] for the README's recipe on a
+  fresh directory (README.md:71).  That rule is the default here too (N is taken once, on rank 0, before any rank writes);
+  the additive flag ``--use_n_layer`` switches to ``hidden_states[--n_layer]``.  One stdout line says which rule is active.
+* whisper script: ``hidden_states[--n_layer]`` (preprocess_whisper.py:71), default -1.
+Either way the forward stops after the state it needs (``last_state``): layers that only feed later states are not launched.
+Additive flags: ``--batch_size``, ``--mode``, ``--checkpoint``, ``--synthetic_weights``, ``--skip_existing``,
+``--use_n_layer``, ``--save_format``, ``--resample``, ``--lora_alpha``, ``--timing``.  ``--seed`` (parsed and unused by the
+reference) seeds the synthetic weights.
 """
 from __future__ import annotations
 
@@ -47,7 +48,7 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
     p.add_argument("--use_average", type=str, default="n")
     # additive
     p.add_argument("--batch_size", type=int, default=16)
-    p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "f16a", "f16q", "f16", "bf16"],
+    p.add_argument("--mode", type=str, default="f16a", choices=["fp32x", "f16a", "f16q", "f16", "bf16"],
                    help="fp32x: fp32-grade results everywhere (~2e-5 of the fp32 reference); f16a: fp32-grade conv stem and "
                         "attention blocks, single-product fp16 feed-forward (within 1e-3 on every stress fixture); f16q: only the "
                         "attention-logit path (q / k projection, QK^T) fp32-grade; f16: fp16 layers throughout (within 1e-3 on "
@@ -66,9 +67,12 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
     p.add_argument("--lora_alpha", type=float, default=16.0,
                    help="LoRA alpha of a fine-tuned --checkpoint (the reference's LoraConfig: r=8, alpha=16)")
     p.add_argument("--timing", action="store_true", help="print where the launching thread spent its time")
+    p.add_argument("--use_n_layer", action="store_true",
+                   help="speech driver: write hidden_states[--n_layer] instead of the reference's rule, hidden_states[number of "
+                        "files found in --save_path at start-up] (preprocess_speech.py:41,67); the whisper driver always honours "
+                        "--n_layer, like the reference's")
     p.add_argument("--compat_layer_quirk", action="store_true",
-                   help="speech driver: index hidden_states with the number of files found in --save_path at "
-                        "start-up, like the reference does")
+                   help="accepted for older command lines: the reference's layer rule is the default now")
     p.add_argument("--synthetic_weights", action="store_true",
                    help="use seeded random weights of the right geometry (no network / benchmarking)")
     return p
@@ -95,6 +99,8 @@ def find_weights(ssl_type: str, checkpoint: str, synthetic: bool, seed: int, geo
     from .weights import load_checkpoint, synthetic_state_dict
     if checkpoint:
         return load_checkpoint(checkpoint, lora_alpha), f"checkpoint {checkpoint}"
+    if not synthetic and os.path.isdir(ssl_type):         # --ssl_type may be a local snapshot directory, as with from_pretrained
+        return load_checkpoint(ssl_type, lora_alpha), f"snapshot {ssl_type}"
     if not synthetic:
         # offline HF cache layout: $HF_HOME/hub/models--org--name/snapshots/<rev>/
         home = os.environ.get("HF_HOME", os.path.join(os.path.expanduser("~"), ".cache", "huggingface"))
@@ -114,7 +120,7 @@ class _Extractor:
     def __init__(self, args, whisper: bool, device: str):
         from .engine import build_encoder
         self.args, self.whisper = args, whisper
-        self.geo = C.geometry_for(args.ssl_type)
+        self.geo = C.resolve_geometry(args.ssl_type, args.checkpoint)      # config.json of the checkpoint, else the built-in table
         if whisper != (self.geo.family == C.FAMILY_WHISPER):
             raise OSError(f"{args.ssl_type} is not a {'whisper' if whisper else 'wav2vec2-style'} encoder")
         from . import dist as D
@@ -131,6 +137,9 @@ class _Extractor:
             raise OSError(err or "rank 0 found no checkpoint")
         sd, self.bcast_s, self.bcast_bytes = D.broadcast_state_dict(sd)
         self.enc = build_encoder(self.geo, sd, device, args.mode)
+        del sd                                                # the fp32 broadcast bucket (views of it) is not needed any more
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
         self.average = args.use_average == "y"
 
     @classmethod
@@ -146,7 +155,7 @@ class _Extractor:
         """One ragged batch -> one CPU [T, D] tensor per utterance (rows a19/a20), synchronously."""
         from .engine import mean_last4
         lengths = [len(w) for w in waves]
-        hs = self.enc.forward(self.enc.upload(waves), lengths)
+        hs = self.enc.forward(self.enc.upload(waves), lengths, last_state=None if self.average else layer_index)
         sel = mean_last4(hs) if self.average else hs.states[layer_index]
         out = []
         host = self.enc.download(sel)
@@ -175,7 +184,7 @@ class _Extractor:
             t0 = clock()
             dev = self.enc.upload(waves, slot)
             t1 = clock()
-            hs = self.enc.forward(dev, lengths, slot=slot)
+            hs = self.enc.forward(dev, lengths, slot=slot, last_state=None if self.average else layer_index)
             t2 = clock()
             sel = mean_last4(hs) if self.average else hs.states[layer_index]
             host = self._pinned_out(slot, sel.shape[0], sel.shape[1])
@@ -215,11 +224,27 @@ class _Extractor:
 LAST_RUN: dict = {}       # counters of the most recent _run in this process (bench.py's end-to-end leg reads them)
 
 
-def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -> int:
+class _NoDist:
+    """``local_only`` runs (bench.py's end-to-end leg at N > 1: every rank extracts ITS OWN directory, weak scaling): the
+    driver behaves as a single process -- no sharding, no collective, the caller's process group is left alone."""
+    @staticmethod
+    def env():
+        from . import dist as D
+        return 0, 1, D.env()[2]
+    init = staticmethod(lambda *a, **k: None)
+    shutdown = staticmethod(lambda: None)
+    broadcast_int = staticmethod(lambda v, *a, **k: int(v))
+    sum_over_ranks = staticmethod(float)
+    max_over_ranks = staticmethod(float)
+
+
+def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, local_only: bool = False) -> int:
     """``extractor_factory(args, whisper, device)`` replaces ``_Extractor`` (bench.py hands in its already-built encoder;
     the CPU gloo tests hand in a stub so that everything around the model call -- sharding, the compat layer index,
     disjoint writes, failure reporting -- runs without a GPU)."""
     from . import dist as D
+    if local_only:
+        D = _NoDist
     args = build_parser(whisper).parse_args(argv)
     rank, world, local_rank = D.env()
     average = args.use_average == "y"
@@ -256,7 +281,7 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
         return 0
     try:
         ex = (extractor_factory or _Extractor)(args, whisper, device)
-    except OSError as e:
+    except (OSError, NotImplementedError) as e:          # NotImplementedError: a config.json variant the encoders refuse
         log(f"Error: No pretrained model found with the name {args.ssl_type}")
         log(f"  ({e})")
         log("Something went wrong, make sure everything is correct before running again!")
@@ -267,12 +292,16 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
     num_states = ex.geo.num_layers + 1
     if average:
         layer_index = None
-    elif args.compat_layer_quirk and not whisper:
+        log("Layer rule: mean of the last four hidden states (--use_average y)")
+    elif not whisper and not args.use_n_layer:
         layer_index = n_existing                         # preprocess_speech.py:41,67 (may be out of range -> per-file failure)
+        log(f"Layer rule: hidden_states[{n_existing}] = hidden_states[number of files found in --save_path at start-up] "
+            f"(the reference's rule, preprocess_speech.py:41,67; --use_n_layer selects hidden_states[--n_layer])")
     else:
         # an out-of-range --n_layer is what ``hidden_states[N]`` raises per file in the reference (IndexError inside
         # the per-file try/except): keep the raw index and let every file report it, instead of crashing here
         layer_index = args.n_layer if args.n_layer >= 0 else num_states + args.n_layer
+        log(f"Layer rule: hidden_states[{args.n_layer}] (--n_layer)")
     bad_layer = layer_index is not None and not 0 <= layer_index < num_states
 
     # Shard the UNFILTERED, deterministic list first; --skip_existing then filters each rank's own shard.  (Filtering
@@ -282,7 +311,11 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
     mine = shard_files(paths, sizes, rank, world)
     if args.skip_existing:
         ext = ".npy" if args.save_format == "npy" else ".pt"
-        mine = [p for p in mine if not os.path.isfile(feature_path(args.save_path, p)[:-3] + ext)]
+
+        def present(p):                                      # outputs are renamed into place when complete; an empty file is not one
+            out = feature_path(args.save_path, p)[:-3] + ext
+            return os.path.isfile(out) and os.path.getsize(out) > 0
+        mine = [p for p in mine if not present(p)]
     batches = make_batches(mine, max(1, args.batch_size))
 
     def decode(path):
@@ -296,7 +329,10 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None) -
         try:
             out = feature_path(args.save_path, path)
             if args.save_format == "npy":
-                np.save(out[:-3] + ".npy", feats.numpy())
+                final = out[:-3] + ".npy"
+                with open(final + ".tmp", "wb") as f:        # complete or absent: --skip_existing trusts what it finds
+                    np.save(f, feats.numpy())
+                os.replace(final + ".tmp", final)
             else:
                 save_feature(feats, out)
         except Exception as e:                            # noqa: BLE001
@@ -487,7 +523,7 @@ def run_roberta(argv: Optional[Sequence[str]] = None, tokenize=None, family: str
     torch.cuda.set_device(local_rank)
     D.init(device=torch.device("cuda", local_rank))
     try:
-        geo = C.geometry_for(args.roberta_type)
+        geo = C.resolve_geometry(args.roberta_type, args.checkpoint)
         if geo.family != family:
             raise OSError(f"{args.roberta_type} is not a {family} encoder")
         if args.max_len > 512:
@@ -539,9 +575,9 @@ def run_deberta(argv: Optional[Sequence[str]] = None, tokenize=None) -> int:
     return run_roberta(argv, tokenize, family=C.FAMILY_DEBERTA)
 
 
-def run_speech(argv: Optional[Sequence[str]] = None, extractor_factory=None) -> int:
-    return _run(argv, whisper=False, extractor_factory=extractor_factory)
+def run_speech(argv: Optional[Sequence[str]] = None, extractor_factory=None, local_only: bool = False) -> int:
+    return _run(argv, whisper=False, extractor_factory=extractor_factory, local_only=local_only)
 
 
-def run_whisper(argv: Optional[Sequence[str]] = None, extractor_factory=None) -> int:
-    return _run(argv, whisper=True, extractor_factory=extractor_factory)
+def run_whisper(argv: Optional[Sequence[str]] = None, extractor_factory=None, local_only: bool = False) -> int:
+    return _run(argv, whisper=True, extractor_factory=extractor_factory, local_only=local_only)

@@ -78,6 +78,7 @@ class Tape:
         self.n = 0
         self.patches = []                    # (struct view inside cmds, field name, size name)
         self.inputs: Dict[str, tuple] = {}   # named per-batch pointers, e.g. the uploaded waveform
+        self.marks: Dict[int, int] = {}      # hidden state index -> number of leading commands that produce states[0..index]
         self._failed = C.c_int32(-1)
 
     def slot(self, union_field: str):
@@ -92,12 +93,26 @@ class Tape:
                 self.patches.append((view, field, value.name))
         self.n += 1
 
-    def run(self, sizes: Dict[str, int], stream: int) -> None:
+    def subset(self, keep) -> "Tape":
+        """Measurement aid (bench.py ``step_decomposition``): a command list holding copies of the recorded launches whose op
+        satisfies ``keep(op)``, with the sizes of the batch that ran last.  Same pointers, same shapes, same kernels -- replayed
+        on its own it shows what ONE class of kernels (the GEMMs, the attention kernels, the row kernels) costs in the regime
+        the step runs them in (two utterance groups on parallel graph branches)."""
+        picked = [i for i in range(self.n) if keep(self.cmds[i].op)]
+        t = Tape(max(1, len(picked)))
+        for j, i in enumerate(picked):
+            C.memmove(C.byref(t.cmds[j]), C.byref(self.cmds[i]), C.sizeof(_lib.Cmd))
+        t.n = len(picked)
+        return t
+
+    def run(self, sizes: Dict[str, int], stream: int, last_state: Optional[int] = None) -> None:
+        """Replay the list; with ``last_state`` only the leading commands that produce hidden states 0..last_state."""
         for view, field, name in self.patches:
             setattr(view, field, sizes[name])
-        rc = lib.ser_run(self.cmds, self.n, C.byref(self._failed), stream)
+        n = self.n if last_state is None else self.marks.get(last_state, self.n)
+        rc = lib.ser_run(self.cmds, n, C.byref(self._failed), stream)
         if rc != 0:
-            check(rc, f"ser_run (command {self._failed.value} of {self.n})")
+            check(rc, f"ser_run (command {self._failed.value} of {n})")
 
 
 def _on_stream(fn):
@@ -148,9 +163,11 @@ class HiddenStates:
     ``states`` is one fp32 tensor [L+1, rows, D]; utterance b owns rows
     frame_offs[b]:frame_offs[b+1] (crop to the true frame count is implicit)."""
 
-    def __init__(self, states: torch.Tensor, frame_offs: Sequence[int]):
+    def __init__(self, states: torch.Tensor, frame_offs: Sequence[int], computed: Optional[int] = None):
         self.states = states
         self.frame_offs = list(int(x) for x in frame_offs)
+        # states[0 .. computed-1] hold this batch's results; a forward stopped early (``last_state``) leaves the rest stale
+        self.computed = states.shape[0] if computed is None else int(computed)
 
     def __len__(self) -> int:
         return self.states.shape[0]
@@ -160,7 +177,10 @@ class HiddenStates:
         return len(self.frame_offs) - 1
 
     def utterance(self, b: int, layer: int) -> torch.Tensor:
-        return self.states[layer, self.frame_offs[b]: self.frame_offs[b + 1]]
+        idx = layer if layer >= 0 else layer + self.states.shape[0]
+        if not 0 <= idx < self.computed:
+            raise IndexError(f"hidden state {layer} is not available (states 0..{self.computed - 1} were computed)")
+        return self.states[idx, self.frame_offs[b]: self.frame_offs[b + 1]]
 
     def frames(self, b: int) -> int:
         return self.frame_offs[b + 1] - self.frame_offs[b]
@@ -191,13 +211,25 @@ class _EncoderBase:
         self._st: Optional[int] = None      # launch stream of the forward in progress (looked up once per forward)
         self._rec: Optional[Tape] = None    # when set, the launch helpers record into it instead of launching
 
+    def _check_last_state(self, last_state: Optional[int]) -> Optional[int]:
+        if last_state is None:
+            return None
+        L = self.geo.num_layers
+        last_state = int(last_state)
+        if not 0 <= last_state <= L:
+            raise IndexError("tuple index out of range")         # what hidden_states[N] raises in the reference
+        return None if last_state == L else last_state
+
     def _s(self) -> int:
         """HIP stream of the current forward: torch.cuda.current_stream() costs ~15 us and a forward makes ~150 launches."""
         return self._st if self._st is not None else _stream()
 
     # ------------------------------------------------------------------ weights
     def _dev_f32(self, t: torch.Tensor) -> torch.Tensor:
-        return t.detach().to(torch.float32).contiguous().to(self.device)
+        """fp32 copy on the device that the encoder OWNS: a state dict that arrived by broadcast is made of views into one flat
+        bucket in HBM (dist.broadcast_state_dict); keeping such a view would pin the whole fp32 checkpoint (1.3 GB WavLM-large,
+        8.6 GB XLS-R-2B) beside the 16-bit planes for the life of the run, and its start is only 4-byte aligned."""
+        return t.detach().to(device=self.device, dtype=torch.float32, copy=True).contiguous()
 
     def _linear(self, w: torch.Tensor, b: Optional[torch.Tensor], stem: bool = False, mode: Optional[int] = None) -> Linear:
         """fp32 [N, K] -> 16-bit operand planes on the device (ser_split_bf16): bf16 hi (+ lo), or fp16 (hi + lo for FP16X)."""
@@ -387,7 +419,7 @@ class _EncoderBase:
         g = groups * ((n_cols + 63) // 64)
         return g + (g & 1)
 
-    def _run_layers(self, pl, states, first_groups: int, B: int, max_frames: int):
+    def _run_layers(self, pl, states, first_groups: int, B: int, max_frames: int, last_state: Optional[int] = None):
         """Pre-LN / stable-LN encoder layers with BOTH LayerNorms deferred into the consuming GEMMs:
         x -> [QKV(+gate) GEMM: LN1 folded] -> attention -> [out GEMM +x -> h] -> [FC1 GEMM: LN2 folded, GELU]
           -> [FC2 GEMM +h -> next x].  Producers emit the bf16 operand copy and the row partial sums, both SHIFTED by
@@ -400,6 +432,14 @@ class _EncoderBase:
         wavlm = geo.family == FAMILY_WAVLM
         gD = self._stat_groups(D)
         gx = first_groups
+        # ``last_state`` = N: the caller reads hidden_states[N] only (the reference's speech script keeps one state,
+        # preprocess_speech.py:67), so the layers that only feed later states are not launched.  Recording a command list marks
+        # where every state is complete instead (Tape.marks), and the replay stops there.
+        rec = self._rec
+        if rec is not None:
+            rec.marks[0] = rec.n
+        elif last_state == 0:
+            return
         self._row_center(states[0], pl["xa"], pl["px0"], pl["sx"], M, D)
         shifted = not _NO_SHIFT
         for i, lay in enumerate(self.layers):
@@ -431,7 +471,20 @@ class _EncoderBase:
                            out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD, out_mode=self.x_mode,
                            shift=(pl["mh"], pl["sx"], lay["fc2_bias_mean"]) if shifted else None)
             gx = gD
+            if not last:
+                if rec is not None:
+                    rec.marks[i + 1] = rec.n
+                elif last_state == i + 1:
+                    return
         self._layernorm(pl["last"], D, self.enc_ln, M, D, out_f32=states[L])
+
+    def recorded_tape(self, lengths: Sequence[int], slot: int) -> Tape:
+        """the command list the slot's last forward over ``lengths`` replayed (SpeechEncoder: per arena; Whisper: per plan)"""
+        pl = self._plan(lengths, slot)
+        tape = pl.get("tape") or getattr(self, "_arenas", {}).get(slot, {}).get("tape")
+        if tape is None:
+            raise _lib.SerHipError("no recorded command list for this slot yet (run a forward first)")
+        return tape
 
     @_on_stream
     def attention_blocks_only(self, lengths: Sequence[int], slot: int) -> int:
@@ -621,7 +674,9 @@ class SpeechEncoder(_EncoderBase):
         # less than on the fp32x stem and, unlike the conv stack and the projection, moves the error by nothing measurable
         # (WavLM-large, K = 128 taps x 64 channels: 6.8e-4 either way; HuBERT-xlarge, 128 x 80: 8.0e-4 either way).  XLS-R-2B's
         # 128 x 120 = 15 360-long sums do feel fp16 operands (7.0e-4 -> 8.3e-4 at full geometry), so they stay on the stem format.
-        self.pos_in_stem = self.mode_name in ("f16", "f16q", "f16a") and Cg * k > 128 * 80
+        # "f16q" / "f16a" keep it on the stem format always: an error in hidden_states[0] enters layer 0's logits, and these modes
+        # exist for attention maps sharp enough to amplify it (LoRA stress fixture: 1.4e-3 -> see DESIGN.md section 4)
+        self.pos_in_stem = (self.mode_name == "f16" and Cg * k > 128 * 80) or self.mode_name in ("f16q", "f16a")
         self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"], stem=self.pos_in_stem)
         self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
         self.layers = []
@@ -799,11 +854,14 @@ class SpeechEncoder(_EncoderBase):
     use_tape = True          # replay recorded command lists (one foreign call per forward); False = launch one by one
 
     @_on_stream
-    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
-        """packed raw samples [sum(lengths)] fp32 on the device -> L+1 hidden states."""
+    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0,
+                last_state: Optional[int] = None) -> HiddenStates:
+        """packed raw samples [sum(lengths)] fp32 on the device -> L+1 hidden states (``last_state`` = N: only states 0..N,
+        the launches that feed later states are skipped)."""
         pl = self._plan(lengths, slot)
+        last_state = self._check_last_state(last_state)
         if not self.use_tape or self.gemm_trace is not None or self.block_trace is not None:
-            self._launches(pl, packed_wave)                  # eager: one Python -> C transition per kernel
+            self._launches(pl, packed_wave, last_state)      # eager: one Python -> C transition per kernel
         else:
             ar = self._arenas[slot]
             tape = ar.get("tape")
@@ -815,10 +873,10 @@ class SpeechEncoder(_EncoderBase):
                     self._rec = None
                 ar["tape"] = tape
             tape.inputs["wav"].wav = packed_wave.data_ptr()
-            tape.run(pl["sizes"], self._s())
-        return HiddenStates(pl["states"], pl["frame_offs_host"])
+            tape.run(pl["sizes"], self._s(), last_state)
+        return HiddenStates(pl["states"], pl["frame_offs_host"], None if last_state is None else last_state + 1)
 
-    def _launches(self, pl, packed_wave: torch.Tensor) -> None:
+    def _launches(self, pl, packed_wave: torch.Tensor, last_state: Optional[int] = None) -> None:
         geo = self.geo
         B, M, D, C0 = pl["B"], pl["M"], geo.hidden, geo.conv_dim[0]
         # a6 + a7 (layer 0): zero-mean / unit-variance per utterance fused with framing, then
@@ -868,7 +926,7 @@ class SpeechEncoder(_EncoderBase):
                    N=Cg, K=geo.pos_conv_kernel * kc, act=_lib.ACT_GELU, residual=pl["proj_f32"], ldr=D,
                    out_f32=states[0], ldo_f32=D, k_algo=geo.pos_conv_kernel * Cg, stem=self.pos_in_stem)
         # a11/a12: stable-LayerNorm encoder layers (LayerNorms deferred into the GEMMs)
-        self._run_layers(pl, states, pl["first_groups"], B, pl["Tmax"])
+        self._run_layers(pl, states, pl["first_groups"], B, pl["Tmax"], last_state)
 
 
 class WhisperEncoder(_EncoderBase):
@@ -902,9 +960,12 @@ class WhisperEncoder(_EncoderBase):
         """Every Whisper shape is a function of B alone (30 s windows), so buffers are keyed by (slot, B) and a new
         batch only uploads its B+1 sample offsets."""
         lengths = tuple(int(n) for n in lengths)
-        pl = self._cache.get((slot, len(lengths)))
+        pl = self._cache.pop((slot, len(lengths)), None)
         if pl is None:
             pl = self._build_plan(len(lengths), slot)
+        else:
+            self._cache[(slot, len(lengths))] = pl      # re-insert: the dict is kept in least-recently-USED order, the hot
+            #                                             full-batch plans of the two pipeline slots are never the ones evicted
         if pl["lengths"] != lengths:
             if pl["offs_evt"] is not None:
                 pl["offs_evt"].synchronize()
@@ -976,14 +1037,17 @@ class WhisperEncoder(_EncoderBase):
     use_tape = True          # replay a recorded command list (one foreign call per forward), like SpeechEncoder
 
     @_on_stream
-    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
+    def forward(self, packed_wave: torch.Tensor, lengths: Sequence[int], slot: int = 0,
+                last_state: Optional[int] = None) -> HiddenStates:
         """packed raw samples -> log-mel (a16) -> encoder (a17): the reference's processor + model.encoder calls
         (preprocess_whisper.py:48,57).  Every buffer is a function of (slot, B), so the ~170 launches are recorded once
-        per plan and replayed with one ser_run call; only the waveform pointer changes from batch to batch."""
+        per plan and replayed with one ser_run call; only the waveform pointer changes from batch to batch.
+        ``last_state`` = N stops after hidden state N (``--n_layer N``, preprocess_whisper.py:71)."""
         pl = self._plan(lengths, slot)
+        last_state = self._check_last_state(last_state)
         if not self.use_tape or self.gemm_trace is not None or self.block_trace is not None:
             self._logmel(pl, packed_wave)
-            self._encoder_launches(pl, pl["mel"])
+            self._encoder_launches(pl, pl["mel"], last_state)
         else:
             tape = pl.get("tape")
             if tape is None:
@@ -995,8 +1059,8 @@ class WhisperEncoder(_EncoderBase):
                     self._rec = None
                 pl["tape"] = tape
             tape.inputs["wav"].wav = packed_wave.data_ptr()
-            tape.run({}, self._s())
-        return HiddenStates(pl["states"], pl["frame_offs_host"])
+            tape.run({}, self._s(), last_state)
+        return HiddenStates(pl["states"], pl["frame_offs_host"], None if last_state is None else last_state + 1)
 
     @_on_stream
     def forward_features(self, input_features: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
@@ -1009,7 +1073,7 @@ class WhisperEncoder(_EncoderBase):
         self._encoder_launches(pl, input_features)
         return HiddenStates(pl["states"], pl["frame_offs_host"])
 
-    def _encoder_launches(self, pl, input_features: torch.Tensor) -> None:
+    def _encoder_launches(self, pl, input_features: torch.Tensor, last_state: Optional[int] = None) -> None:
         geo = self.geo
         B, M, D, nm = pl["B"], pl["M"], geo.hidden, geo.n_mels
         T1, T2 = self.N_FRAMES, geo.max_source_positions
@@ -1029,7 +1093,7 @@ class WhisperEncoder(_EncoderBase):
         states = pl["states"]
         self._gemm(pl["c1_act"], self.conv2, M, a_rowoff=pl["c2_rowoff"], act=_lib.ACT_GELU, residual=self.pos_emb,
                    ldr=D, res_row_mod=T2, out_f32=states[0], ldo_f32=D, stem=True)
-        self._run_layers(pl, states, pl["first_groups"], B, T2)
+        self._run_layers(pl, states, pl["first_groups"], B, T2, last_state)
 
 
 class TextEncoder(_EncoderBase):

@@ -133,10 +133,21 @@ def save_feature(feats: torch.Tensor, path: str) -> None:
     if t.device.type != "cpu":
         t = t.cpu()
     t = t.to(torch.float32).contiguous()
-    if t.dim() == 2 and t.shape[1] > 0:
-        # same archive torch.save writes, produced by libserhip's ser_pt_write_f32 without the GIL: the writer threads
-        # of the driver no longer serialise on the interpreter (pickler + Python zip bookkeeping of torch.save)
-        from ._lib import check, lib
-        check(lib.ser_pt_write_f32(os.fsencode(path), t.data_ptr(), t.shape[0], t.shape[1]), "ser_pt_write_f32")
-        return
-    torch.save(t.clone(), path)
+    # written under a temporary name and renamed when complete: a killed process or a full disk leaves no truncated <name>.pt
+    # for --skip_existing (which only asks whether the file exists) to mistake for a finished one
+    tmp = path + ".tmp"
+    try:
+        if t.dim() == 2 and t.shape[1] > 0:
+            # same archive torch.save writes, produced by libserhip's ser_pt_write_f32 without the GIL: the writer threads
+            # of the driver no longer serialise on the interpreter (pickler + Python zip bookkeeping of torch.save)
+            from ._lib import check, lib
+            check(lib.ser_pt_write_f32(os.fsencode(tmp), t.data_ptr(), t.shape[0], t.shape[1]), "ser_pt_write_f32")
+        else:
+            torch.save(t.clone(), tmp)
+        os.replace(tmp, path)
+    except BaseException:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+        raise

@@ -22,7 +22,7 @@ def _worker(rank, world, port, out_dir):
     assert D.init("gloo") == (rank, world, rank)
     sd = synthetic_state_dict(C.TINY_WAVLM, 5) if rank == 0 else None
     sd, dt, nbytes = D.broadcast_state_dict(sd)
-    assert nbytes == sum(v.numel() for v in sd.values()) * 4 and dt >= 0
+    assert nbytes == sum((v.numel() + 3) // 4 * 4 for v in sd.values()) * 4 and dt >= 0     # entries padded to 16-byte boundaries
     digest = state_dict_digest(sd)
     n = D.broadcast_int(17 if rank == 0 else -1)
     files = [f"f{i}" for i in range(9)]

@@ -39,10 +39,13 @@ def test_speech_driver_config0(tmp_path, capsys):
         waves[f"syn_{i:04d}"] = write_wav(wav_dir / f"syn_{i:04d}.wav", synth(7 + i, n))
     (wav_dir / "broken.wav").write_bytes(b"not a wav file")
     write_wav(wav_dir / "syn_0003b_tiny.wav", synth(99, 300))       # decodes, but is shorter than the receptive field:
+    # the README recipe (README.md:71) on a fresh directory: the reference's rule gives hidden_states[0] (0 files found at
+    # start-up, preprocess_speech.py:41,67) whatever --n_layer says -- and the forward stops after that state
     rc = driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", str(wav_dir), "--save_path", str(out),
-                            "--synthetic_weights", "--n_layer", "0", "--batch_size", "5"])
+                            "--synthetic_weights", "--n_layer", "12", "--batch_size", "5"])
     text = capsys.readouterr().out                                    # its batch falls back to one-by-one, neighbours survive
     assert rc == 0
+    assert "Layer rule: hidden_states[0]" in text and "reference's rule" in text
     assert "Using device = cuda" in text and "10 file are going to be processed..." in text
     assert "Failed to process" in text and "broken.wav" in text      # logged and skipped, like the reference
     assert "syn_0003b_tiny.wav" in text and "receptive field" in text
@@ -60,10 +63,10 @@ def test_speech_driver_config0(tmp_path, capsys):
         assert float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
     assert tuple(torch.load(out / "syn_0000.pt").shape) == (149, 1024)
 
-    # compat quirk: 8 files now in save_path -> hidden_states[8]; and --use_average
+    # the reference's rule on a re-run: 8 files now in save_path -> hidden_states[8]
     rc = driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", str(wav_dir), "--save_path", str(out),
-                            "--synthetic_weights", "--compat_layer_quirk", "--batch_size", "8"])
-    assert rc == 0
+                            "--synthetic_weights", "--batch_size", "8"])
+    assert rc == 0 and "Layer rule: hidden_states[8]" in capsys.readouterr().out
     got = torch.load(out / "syn_0001.pt")
     with torch.no_grad():
         ref = O.extract_speech(geo, sd, waves["syn_0001"], layer_index=8)
@@ -80,6 +83,41 @@ def test_speech_driver_config0(tmp_path, capsys):
             ref = O.extract_speech(geo, sd, waves[name], use_average=True)
         assert got.shape == ref.shape
         assert float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
+
+
+def test_early_exit_states_are_bit_equal_to_the_full_forward():
+    """``last_state`` = N launches only what hidden_states[0..N] need (the reference keeps one state per utterance,
+    preprocess_speech.py:67 / preprocess_whisper.py:71): the states it leaves are bit-equal to the full forward's, through
+    the recorded command list (partial replay) and launch by launch, for the speech and the Whisper encoder."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder, WhisperEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    for geo, cls in ((C.TINY_WAVLM, SpeechEncoder), (C.TINY_HUBERT, SpeechEncoder), (C.TINY_WHISPER, WhisperEncoder)):
+        sd = synthetic_state_dict(geo, 3)
+        waves = [synth(5, 9000).astype(np.float32), synth(6, 16000).astype(np.float32)]
+        lens = [len(w) for w in waves]
+        for mode in ("f16a", "bf16"):
+            enc = cls(geo, sd, "cuda:0", mode=mode)
+            full = enc.forward(enc.upload(waves), lens)
+            torch.cuda.synchronize()
+            ref = full.states.clone()
+            L = geo.num_layers
+            for use_tape in (True, False):
+                enc.use_tape = use_tape
+                for n in range(L + 1):
+                    full.states.fill_(float("nan"))
+                    hs = enc.forward(enc.upload(waves), lens, last_state=n)
+                    torch.cuda.synchronize()
+                    assert hs.computed == n + 1 if n < L else hs.computed == L + 1
+                    assert torch.equal(hs.states[: n + 1], ref[: n + 1]), (geo.name, mode, use_tape, n)
+                    if n < L:
+                        assert torch.isnan(hs.states[n + 1:]).all()                   # nothing beyond state n was launched
+                        with pytest.raises(IndexError):
+                            hs.utterance(0, n + 1)
+                        with pytest.raises(IndexError):
+                            hs.utterance(0, -1)
+            with pytest.raises(IndexError):
+                enc.forward(enc.upload(waves), lens, last_state=L + 1)
 
 
 def test_whisper_driver_crop(tmp_path, capsys):
@@ -123,7 +161,7 @@ def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
         return ids, mask
 
     assert driver.run_speech(["--ssl_type", "facebook/hubert-xlarge-ll60k", "--wav_dir", str(wav_dir), "--save_path", str(d1),
-                              "--synthetic_weights", "--mode", "bf16", "--n_layer", "-1", "--batch_size", "3"]) == 0
+                              "--synthetic_weights", "--mode", "bf16", "--use_n_layer", "--n_layer", "-1", "--batch_size", "3"]) == 0
     assert driver.run_roberta(["--roberta_type", "roberta-large", "--df_path", str(csv), "--save_path", str(d2),
                                "--synthetic_weights", "--mode", "bf16"], tokenize=tok) == 0
     assert sorted(os.listdir(d1)) == sorted(os.listdir(d2)) == [n.replace(".wav", ".pt") for n in names]
@@ -140,6 +178,78 @@ def test_config4_plumbing_speech_plus_text_into_the_head(tmp_path, capsys):
     assert logits.shape == (4, 8) and torch.isfinite(logits).all()
     loss = torch.nn.CrossEntropyLoss()(logits, batch["label"].max(dim=1)[1].long())
     assert torch.isfinite(loss)
+
+
+def test_config4_extract_train_eval_end_to_end(tmp_path, capsys):
+    """BASELINE.json configs[4] closed end to end: 64 synthetic clips + transcripts -> preprocess_speech (HuBERT-xlarge) and
+    preprocess_roberta (RoBERTa-large) write the two lazy dirs -> the train counterpart (interspeech_ser_amd/head.py,
+    bin/train_cat_bimodal_lazy_1head.py here) runs 2 epochs from a reference-style config JSON and saves the best-F1
+    ``multimodal_ser.pt`` -> the eval counterpart writes results/dev.csv.  The checkpoint is a checkpoint of the REFERENCE head:
+    it loads strictly into the restated class that tests/golden/fusion_head_pins.npz pins to the reference's own definition and
+    gives the same logits as the product model (/root/reference does not exist on this box; the CPU suite loads the same kind
+    of checkpoint into the reference's class itself)."""
+    import json
+    import pandas as pd
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd import head as HD
+    from oracle import fusion_head as H
+    wav_dir, d1, d2 = tmp_path / "Audios", tmp_path / "hubert_xlarge", tmp_path / "roberta_large"
+    wav_dir.mkdir()
+    rng = np.random.default_rng(99)
+    names = [f"MSP-PODCAST_{i:04d}.wav" for i in range(64)]
+    cls = rng.integers(0, 8, 64)
+    words = ["angry", "sad", "happy", "wow", "scared", "yuck", "pff", "okay"]
+    for i, n in enumerate(names):
+        x = synth(100 + i, int(rng.integers(16000, 48000)))
+        write_wav(wav_dir / n, x * (0.5 + 0.2 * cls[i]))                 # a (weak) class cue in the level
+    lab = pd.DataFrame(np.eye(8, dtype=np.float32)[cls], columns=HD.CLASSES)
+    lab.insert(0, "FileName", names)
+    lab["Split_Set"] = ["Train" if i % 4 else "Development" for i in range(64)]
+    lab.to_csv(tmp_path / "processed_labels.csv", index=False)
+    pd.DataFrame({"FileName": names, "transcription": [" ".join([words[c]] * (1 + i % 5)) for i, c in enumerate(cls)]}).to_csv(
+        tmp_path / "transcripts.csv", index=False)
+
+    def tok(texts, max_len=80):
+        ids = torch.full((len(texts), max_len), 1, dtype=torch.int64)
+        mask = torch.zeros((len(texts), max_len), dtype=torch.int64)
+        for i, t in enumerate(texts):
+            toks = [0] + [3 + 7 * words.index(w) for w in t.split()] + [2]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return ids, mask
+
+    assert driver.run_speech(["--ssl_type", "facebook/hubert-xlarge-ll60k", "--wav_dir", str(wav_dir), "--save_path", str(d1),
+                              "--synthetic_weights", "--mode", "bf16", "--use_n_layer", "--n_layer", "-1"]) == 0
+    assert driver.run_roberta(["--roberta_type", "roberta-large", "--df_path", str(tmp_path / "transcripts.csv"), "--save_path", str(d2),
+                               "--synthetic_weights", "--mode", "bf16"], tokenize=tok) == 0
+    assert len(os.listdir(d1)) == len(os.listdir(d2)) == 64
+    cfg = {"wav_dir": str(wav_dir), "txt_dir": str(tmp_path / "transcripts.csv"), "lazy_dir1": str(d1), "lazy_dir2": str(d2),
+           "label_path": str(tmp_path / "processed_labels.csv"), "feat1_dim": 1280, "feat2_dim": 1024, "use_balanced_batch": False,
+           "use_focalloss": False, "epochs": 2, "lr": 1e-4, "model_path": str(tmp_path / "experiments" / "head1"), "batch_size": 16,
+           "accum_step": 1}
+    cfg_path = tmp_path / "config_cat_bimodal_lazy_lr1e4_hubertxlarge_roberta_head1.json"
+    cfg_path.write_text(json.dumps(cfg))
+    capsys.readouterr()
+    assert HD.main(["--config_path", str(cfg_path), "--seed", "7"]) == 0                       # bin/train_cat_bimodal_lazy_1head.py
+    assert HD.main(["--config_path", str(cfg_path), "--seed", "7"], evaluate_only=True) == 0   # bin/eval_cat_bimodal_lazy_1head.py
+    ck = os.path.join(cfg["model_path"], "multimodal_ser.pt")
+    sd = torch.load(ck, map_location="cpu")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fusion_head_pins.npz"))
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]                                      # the reference's 42 keys, in order
+    assert [tuple(v.shape) for v in sd.values()] == [tuple(int(x) for x in str(sh).split(",")) for sh in g["shapes"]]
+    rows = list(__import__("csv").reader(open(os.path.join(cfg["model_path"], "results", "dev.csv"))))
+    assert len(rows) == 17 and rows[0][:2] == ["Filename", "Prediction"]
+    batch = HD.collate_fn([HD.MultiLabelAudioDataset(names[:4], np.eye(8)[cls[:4]], str(d1), str(d2))[i] for i in range(4)])
+    mine, pinned = HD.MultiModalEmotionClassifier(1280, 1024).eval(), H.MultiModalEmotionClassifier(1280, 1024, 512, 8, 0.5).eval()
+    mine.load_state_dict(sd, strict=True)
+    pinned.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        a, b = mine(batch["feat1"], batch["feat2"]), pinned(batch["feat1"], batch["feat2"])
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-4
+    # the CSV's logits are the evaluation run's (GPU) logits of the same checkpoint
+    dev_names = [n for i, n in enumerate(names) if i % 4 == 0]
+    assert [r[0] for r in rows[1:]] == dev_names
+    assert all(r[1] in HD.CLASS_LETTERS and len(r) == 10 and all(np.isfinite(float(x)) for x in r[2:]) for r in rows[1:])
 
 
 @pytest.mark.parametrize("family,mode", [("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16a"), ("hubert", "f16a"),
@@ -186,7 +296,7 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
     C._REGISTRY["tiny-lora-test"] = geo
     try:
         rc = driver.run_speech(["--ssl_type", "tiny-lora-test", "--wav_dir", str(wav_dir), "--save_path", str(out),
-                                "--checkpoint", str(ck), "--mode", mode, "--n_layer", "-1", "--lora_alpha", "16"])
+                                "--checkpoint", str(ck), "--mode", mode, "--use_n_layer", "--n_layer", "-1", "--lora_alpha", "16"])
     finally:
         C._REGISTRY.pop("tiny-lora-test")
     assert rc == 0, capsys.readouterr().out

@@ -39,6 +39,67 @@ def test_geometry_registry():
         C.geometry_for("no/such-model")
 
 
+def test_geometry_from_config_json(tmp_path):
+    """a3: the reference builds its model from the checkpoint's own config.json (AutoModel.from_pretrained,
+    preprocess_speech.py:111-112), so any name works.  HF's config classes give the field names: a geometry written out
+    through them and read back through geometry_from_config is the same geometry; unsupported variants raise OSError (the class
+    the driver reports as "No pretrained model found"); a snapshot directory under an unknown name resolves."""
+    tf = pytest.importorskip("transformers")
+    import dataclasses
+    import json
+
+    def speech_cfg(geo):
+        common = dict(hidden_size=geo.hidden, num_hidden_layers=geo.num_layers, num_attention_heads=geo.heads,
+                      intermediate_size=geo.ffn, conv_dim=list(geo.conv_dim), conv_kernel=list(geo.conv_kernel),
+                      conv_stride=list(geo.conv_stride), conv_bias=geo.conv_bias, feat_extract_norm="layer", do_stable_layer_norm=True,
+                      num_conv_pos_embeddings=geo.pos_conv_kernel, num_conv_pos_embedding_groups=geo.pos_conv_groups,
+                      layer_norm_eps=geo.layer_norm_eps)
+        if geo.family == C.FAMILY_WAVLM:
+            return tf.WavLMConfig(num_buckets=geo.num_buckets, max_bucket_distance=geo.max_bucket_distance, **common)
+        if geo.family == C.FAMILY_WAV2VEC2:
+            return tf.Wav2Vec2Config(**common)
+        return tf.HubertConfig(feat_proj_layer_norm=True, **common)
+
+    def same(a, b):
+        return all(getattr(a, f.name) == getattr(b, f.name) for f in dataclasses.fields(a) if f.name != "name")
+
+    for geo in (C.WAVLM_LARGE, C.XLSR_2B, C.HUBERT_XLARGE, C.TINY_WAVLM, C.TINY_WAV2VEC2, C.TINY_HUBERT):
+        assert same(C.geometry_from_config(speech_cfg(geo).to_dict()), geo), geo.name
+    g = C.WHISPER_LARGE_V3
+    wcfg = tf.WhisperConfig(num_mel_bins=g.n_mels, d_model=g.hidden, encoder_layers=g.num_layers, encoder_attention_heads=g.heads,
+                            encoder_ffn_dim=g.ffn, max_source_positions=g.max_source_positions)
+    assert same(C.geometry_from_config(wcfg.to_dict()), g)
+    g = C.ROBERTA_LARGE
+    rcfg = tf.RobertaConfig(vocab_size=g.vocab_size, hidden_size=g.hidden, num_hidden_layers=g.num_layers, num_attention_heads=g.heads,
+                            intermediate_size=g.ffn, max_position_embeddings=g.max_positions, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1)
+    assert same(C.geometry_from_config(rcfg.to_dict()), g)
+    for g in (C.DEBERTA_V3_LARGE, C.DEBERTA_V2_XLARGE):
+        dcfg = tf.DebertaV2Config(vocab_size=g.vocab_size, hidden_size=g.hidden, num_hidden_layers=g.num_layers, num_attention_heads=g.heads,
+                                  intermediate_size=g.ffn, max_position_embeddings=512, type_vocab_size=0, layer_norm_eps=1e-7, pad_token_id=0,
+                                  relative_attention=True, position_buckets=256, norm_rel_ebd="layer_norm", share_att_key=True,
+                                  pos_att_type=["p2c", "c2p"], position_biased_input=False,
+                                  **({"conv_kernel_size": 3, "conv_act": "gelu"} if g.text_conv_kernel else {}))
+        assert same(C.geometry_from_config(dcfg.to_dict()), g), g.name
+    # refused variants
+    for bad in (dict(feat_extract_norm="group"), dict(do_stable_layer_norm=False)):
+        d = speech_cfg(C.WAVLM_LARGE).to_dict()
+        d.update(bad)
+        with pytest.raises(OSError):
+            C.geometry_from_config(d, name="some/fine-tune")
+    with pytest.raises(OSError):
+        C.geometry_from_config({"model_type": "bert"})
+    # a local snapshot under a name the table does not know: directory as --ssl_type, or unknown name + --checkpoint
+    snap = tmp_path / "my-wavlm-finetune"
+    snap.mkdir()
+    (snap / "config.json").write_text(json.dumps(speech_cfg(C.TINY_WAVLM).to_dict()))
+    assert same(C.resolve_geometry(str(snap)), C.TINY_WAVLM)
+    assert same(C.resolve_geometry("acme/wavlm-large-ser-v7", str(snap)), C.TINY_WAVLM)
+    assert same(C.resolve_geometry("acme/wavlm-large-ser-v7", str(snap / "model.safetensors")), C.TINY_WAVLM)
+    with pytest.raises(OSError):
+        C.resolve_geometry("acme/wavlm-large-ser-v7")                     # no config.json, not in the table
+    assert C.resolve_geometry("microsoft/wavlm-large") is C.WAVLM_LARGE      # table fallback
+
+
 def test_deberta_v2_xlarge_geometry_is_registered():
     """The checkpoint the reference's README names for preprocess_deroberta.py (README.md:66): 24 x 1536, 24 heads of 64,
     ConvLayer with kernel 3; 884.6 M parameters with HF's DebertaV2Model at these values."""
@@ -325,18 +386,52 @@ def test_driver_save_format_npy_and_bad_layer_report(tmp_path, capsys):
     for i, n in enumerate((4000, 6000, 9000)):
         write_wav(wav_dir / f"u{i}.wav", 0.1 * rng.standard_normal(n))
     out = tmp_path / "npy"
-    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--save_format", "npy", "--n_layer", "1"],
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--save_format", "npy", "--use_n_layer", "--n_layer", "1"],
                        whisper=False, extractor_factory=Stub) == 0
     assert sorted(os.listdir(out)) == ["u0.npy", "u1.npy", "u2.npy"]
     a = np.load(out / "u1.npy")
     assert a.dtype == np.float32 and a.shape == (C.TINY_WAVLM.frames_for(6000), 4) and float(a[0, 0]) == 1.0
     capsys.readouterr()
     out2 = tmp_path / "bad"
-    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out2), "--n_layer", "7"], whisper=False,
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out2), "--use_n_layer", "--n_layer", "7"], whisper=False,
                        extractor_factory=Stub) == 0
     log = capsys.readouterr().out
     assert log.count("tuple index out of range") == 3 and os.listdir(out2) == []
     assert "SER_RUN " in log
+
+
+def test_default_layer_rule_is_the_reference_rule(tmp_path, capsys):
+    """a19: the reference's speech script ignores --n_layer and writes hidden_states[N], N = files found in --save_path at
+    start-up (preprocess_speech.py:41,67): hidden_states[0] on a fresh directory (README.md:71), [3] on a re-run over three
+    outputs.  The whisper script honours --n_layer (preprocess_whisper.py:71).  --use_n_layer is the additive override."""
+    class Stub:
+        pipelined = False
+
+        def __init__(self, args, whisper, device):
+            self.geo = C.with_layers(C.TINY_WAVLM, 6) if not whisper else C.TINY_WHISPER
+            self.weight_source = "stub"
+
+        def extract(self, waves, layer_index):
+            return [torch.full((3, 4), float(layer_index)) for _ in waves]
+
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        write_wav(wav_dir / f"u{i}.wav", 0.1 * rng.standard_normal(4000))
+    out = tmp_path / "pt"
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--n_layer", "5"], whisper=False, extractor_factory=Stub) == 0
+    log = capsys.readouterr().out
+    assert "Layer rule: hidden_states[0]" in log and "preprocess_speech.py:41,67" in log
+    assert float(torch.load(out / "u1.pt")[0, 0]) == 0.0
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out)], whisper=False, extractor_factory=Stub) == 0
+    assert "Layer rule: hidden_states[3]" in capsys.readouterr().out and float(torch.load(out / "u1.pt")[0, 0]) == 3.0
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--use_n_layer", "--n_layer", "5"], whisper=False,
+                       extractor_factory=Stub) == 0
+    assert "Layer rule: hidden_states[5] (--n_layer)" in capsys.readouterr().out and float(torch.load(out / "u2.pt")[0, 0]) == 5.0
+    outw = tmp_path / "ptw"
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(outw), "--n_layer", "1"], whisper=True, extractor_factory=Stub) == 0
+    assert "Layer rule: hidden_states[1] (--n_layer)" in capsys.readouterr().out and float(torch.load(outw / "u0.pt")[0, 0]) == 1.0
 
 
 def test_driver_on_an_empty_directory(tmp_path, capsys):

@@ -5,20 +5,22 @@
 # (separate passes for FETCH_SIZE / WRITE_SIZE / SQ counters, --kernel-trace only, as the MI355X guide prescribes).
 # Raw output under gpurun_out/prof/, summaries under profiles/<tag>_*.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof
 mkdir -p $OUT profiles
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 FLAGS="--no-trace --no-cpu-baseline --no-parity --no-e2e"
 stats() {  # name, bench args...
     local name=$1; shift
+    rm -rf $OUT/$name                       # rocprofv3 -d accumulates one subdirectory per run: never stamp a stale CSV
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py $FLAGS "$@" > $OUT/$name.json 2> $OUT/$name.err || return 1
-    local f=$(ls $OUT/$name/*/*kernel_stats.csv | head -1)
+    local f=$(ls -t $OUT/$name/*/*kernel_stats.csv | head -1)
     cp "$f" profiles/${TAG}_kernel_stats_$name.csv
     cp $OUT/$name.json profiles/${TAG}_bench_under_rocprof_$name.json
     echo "== $name: $(python3 -c "import json;d=json.load(open('$OUT/$name.json'));print(d['value'], d['unit'], d['config']['ms_per_batch'], 'ms/batch', d.get('verified'))")"
     head -8 "$f" | cut -c1-150
 }
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_l2 $OUT/wpmc_fetch $OUT/wpmc_write
 PMC="--steps 2 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS"
 if [ "$2" = "traffic" ]; then   # only the two traffic passes: re-stamp profiles/<tag>_pmc_traffic.json after a kernel-source change
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
