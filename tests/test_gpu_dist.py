@@ -38,17 +38,18 @@ held = torch.cuda.memory_allocated() - base
 assert held >= nbytes
 waves = [(0.1 * np.random.default_rng(i).standard_normal(n)).astype(np.float32) for i, n in enumerate((16000, 9000))]
 lens = [len(w) for w in waves]
-enc_b = SpeechEncoder(geo, out, "cuda:0", mode="f16a")                            # from the device-resident bucket
+enc_b = SpeechEncoder(geo, out, "cuda:0", mode="fp32x")                           # from the device-resident bucket
 before = torch.cuda.memory_allocated()
 del out
 torch.cuda.synchronize()
 freed = before - torch.cuda.memory_allocated()
 assert freed >= nbytes, (freed, nbytes)                                            # the encoder kept no view of the bucket
-enc_c = SpeechEncoder(geo, sd, "cuda:0", mode="f16a")                             # from the CPU state dict
+enc_c = SpeechEncoder(geo, sd, "cuda:0", mode="fp32x")                            # from the CPU state dict
 a = enc_b.forward(enc_b.upload(waves), lens).states.clone()
 b = enc_c.forward(enc_c.upload(waves), lens).states
 torch.cuda.synchronize()
-assert torch.equal(a, b)
+err = float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+assert err < 2e-5, err            # the fp64 load-time folds ran on the device instead of the host: last-bit differences only
 D.shutdown()
 print("RCCL_SINGLE_RANK_OK", nbytes, freed)
 """
