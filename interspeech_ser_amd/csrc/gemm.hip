@@ -820,6 +820,15 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         // k-step (0.33 LDS fragment reads per MFMA against 0.5 for the 32x64 wave tile below), one ping-pong phase per K tile
         static const long x32_256_min = [] { const char* e = getenv("SER_GEMM_X32_256_MIN"); return e ? atol(e) : 100L; }();   // 100: M = 3992 out-proj / FC2 (128 tiles) gain, M = 1996 ones (64 tiles) lose
         const long t256x128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128) * a->groups;
+        // Largest grids (round 3): 256x256 tiles of 64x128 wave tiles, both planes of a 32-deep K tile per stage, 2 stages (128 KiB):
+        // 24 fragments feed 96 MFMAs per K tile (0.25 LDS fragment reads per MFMA, half the L2 -> LDS bytes per product of the
+        // 256x128 tile), the weight fragments taken in two halves like the LayerNorm tile's (PPW).  From SER_GEMM_X32_SQ_MIN tiles.
+        static const long x32_sq_min = [] { const char* e = getenv("SER_GEMM_X32_SQ_MIN"); return e ? atol(e) : 150L; }();
+        const long t256sq = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
+        // Measured on the step (two A/B pairs, one box): the packed QKV projection on it f16a 1 110 / 1 114 -> 1 134 / 1 130 utt/s; FC1 too
+        // (its GELU epilogue on 128 accumulators + 64 spilled bias / column-sum registers) gives the gain back: fp32x 848 -> 846.
+        // Hence only launches without an activation take it.
+        if (x32_sq_min > 0 && a->N >= 256 && t256sq >= x32_sq_min && a->act == SER_ACT_NONE) return launch_cfg<4, 2, 4, 8, 32, 2, false, true>(a, s);
         if (x32_256_min > 0 && a->N >= 128 && t256x128 >= x32_256_min) return launch_cfg<4, 2, 4, 4, 32, 3, false, true>(a, s);
         return launch_cfg<4, 2, 2, 4, 64, 2, false, true>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
     }

@@ -34,6 +34,23 @@ def planes_value(t):
     return t.double().sum(0)
 
 
+@pytest.mark.parametrize("mode", [2, 4])
+@pytest.mark.parametrize("M,N,K", [(3000, 3104, 192), (2700, 3592, 64), (3992, 3104, 320)])
+def test_gemm_two_plane_256x256_tile_integer_exact(L, mode, M, N, K):
+    """>= 150 tiles of 256 x 256: FP32X / FP16X launches take the 256 x 256 two-plane tile (64 x 128 wave tiles, weight fragments
+    in two halves) -- ragged M / N edges, 2..10 K tiles of 32, with bias."""
+    assert ((M + 255) // 256) * ((N + 255) // 256) >= 150
+    from test_gpu_kernels import to_act
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    ref = A.double() @ W.double().T + bias.double()
+    a, w = (split_h(A), split_h(W)) if mode == 4 else (to_act(A, 2), to_act(W, 2))
+    out, _ = run_gemm(L, a, w, M, N, K, mode, bias=bias.to(DEV))
+    assert torch.equal(out.cpu().double(), ref)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (515, 392, 1024), (2561, 1288, 192), (3000, 1160, 320)])
 def test_gemm_fp16x_integer_exact(L, M, N, K):
     """Small integers are exact in fp16: any slip in the two-plane stage layout or the fragment order shows as a wrong
