@@ -10,8 +10,9 @@ over one batch of 16 synthetic 10 s clips already resident in HBM (BASELINE.json
 Utterances shard across ranks with no data-path collective (weak scaling): the only RCCL
 traffic is the one-time broadcast of the frozen weights from rank 0.
 
-A counted step replays `--reps` such batches back to back (default 8, stated in `config`), so that the timed
-region of the default run lasts > 1 s and a GPU-busy sampler can see it; `value` counts every utterance.
+A counted step covers `--reps` such batches (default 8, stated in `config`), so that the timed region of the default run
+lasts > 1 s and a GPU-busy sampler can see it; `value` counts every utterance.  Round 3: `--inflight` whole batches (default 2)
+run at once on parallel branches of one hipGraph, as the drivers' two-slot pipeline does with real files.
 
 One JSON line on rank 0: metric/value/unit + `roofline` (dominant kernel = the MFMA GEMM, live HIP-event
 timing) + `verified` / `verification` (the outputs of the very graph that was timed, checked after the timed
@@ -105,7 +106,8 @@ def bench_text(args, geo, rank, world, device, D):
     ids[torch.arange(T)[None, :] >= lens[:, None]] = geo.pad_token_id
     ids_d, kl_d = ids.to(device=device, dtype=torch.int32), lens.to(device=device, dtype=torch.int32)
     # like the speech step: the batch runs as `micro` groups of texts on parallel branches of one hipGraph
-    micro = args.micro if 1 < args.micro <= args.batch else 1
+    micro = (args.micro if args.micro > 0 else 2)                  # default: two groups of texts
+    micro = micro if 1 < micro <= args.batch else 1
     cuts = [round(i * args.batch / micro) for i in range(micro + 1)]
     parts = [(ids_d[a:b].contiguous(), kl_d[a:b].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])]
     for slot, (i_, k_) in enumerate(parts):
@@ -284,8 +286,11 @@ def main():
     ap.add_argument("--e2e-workers", type=int, default=4, help="host threads of the end-to-end leg (reference default 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--split", type=str, default="", help="explicit utterance-group sizes, e.g. 9,7 (overrides --micro)")
-    ap.add_argument("--micro", type=int, default=2,
-                    help="split the batch into this many utterance groups run as parallel graph branches")
+    ap.add_argument("--micro", type=int, default=0,
+                    help="split every batch into this many utterance groups run as parallel graph branches")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="whole batches in flight at once, one hipGraph branch (HIP stream) each -- the drivers' two-slot pipeline; "
+                         "--inflight 1 --micro 2 is the round-1/2 form (one batch split into two groups of 8)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -312,20 +317,30 @@ def main():
     if geo.family in (C.FAMILY_ROBERTA, C.FAMILY_DEBERTA):
         return bench_text(args, geo, rank, world, device, D)
     num_samples = int(round(args.seconds * 16000))
-    reps = max(1, args.reps)
+    # defaults (0): two whole batches in flight for the wav2vec2-style encoders (WavLM-large +2.6..4.3 %, HuBERT-xlarge +2.6 %, XLS-R-2B
+    # +5.6 % over one batch split in two groups, same box); Whisper's 30 s windows (M = 24 000 rows per batch) prefer one batch as two
+    # groups of 8 (394 against 381 utt/s)
+    if args.inflight <= 0:
+        args.inflight = 1 if whisper else 2
+    if args.micro <= 0:
+        args.micro = 2 if (whisper and args.inflight == 1) else 1
+    inflight = max(1, args.inflight)
+    reps = max(1, args.reps // inflight)               # replays per counted step: a step stays `--reps` batches (8) back to back
 
     sd, bcast_s = broadcast_weights(geo, 0, rank)
     enc = build_encoder(geo, sd, device, args.mode)
     if world > 1:
         sd = None                  # views of the fp32 broadcast bucket: dropping them frees it (weights stay 1x in HBM)
         torch.cuda.empty_cache()
-    waves = synth_batch(args.batch, num_samples, 1234 + rank)
+    batches_waves = [synth_batch(args.batch, num_samples, 1234 + rank + 7919 * j) for j in range(inflight)]
+    waves = batches_waves[0]
     lengths = [num_samples] * args.batch
     packed = enc.upload(waves)
     torch.cuda.synchronize()
 
-    # The batch is processed as `micro` utterance groups (parallel branches of one hipGraph): every
-    # launch of the step, timed or traced, has the group's shape.
+    # `inflight` whole batches run at once, each on its own branch of one hipGraph (round 3: measured +4.3 % over one batch
+    # split into two groups of 8, same box -- the launches have the shape BASELINE.json's config names, batch = 16, and the
+    # second batch fills what the first leaves idle).  `micro` > 1 additionally splits every batch into utterance groups.
     micro = args.micro if 1 < args.micro <= args.batch else 1
     per = -(-args.batch // micro)                                   # uneven splits allowed: 16 -> 6 + 5 + 5
     cuts = [round(i * args.batch / micro) for i in range(micro + 1)]
@@ -335,9 +350,10 @@ def main():
         micro, cuts = len(sizes), [sum(sizes[:i]) for i in range(len(sizes) + 1)]
         per = max(sizes)
     spans = list(zip(cuts[:-1], cuts[1:]))
+    branches = [(j, a, b) for j in range(inflight) for (a, b) in spans]       # one graph branch (slot, stream) each
 
     def make_groups(e):
-        return [(e.upload(waves[a:b], slot=slot), lengths[a:b]) for slot, (a, b) in enumerate(spans)]
+        return [(e.upload(batches_waves[j][a:b], slot=slot), lengths[a:b]) for slot, (j, a, b) in enumerate(branches)]
 
     groups = make_groups(enc)
     torch.cuda.synchronize()
@@ -409,11 +425,12 @@ def main():
         torch.cuda.synchronize()
         blocks, enc.block_trace = enc.block_trace, None
         # ... and once more with the whole batch in ONE launch per kernel (the shape BASELINE.json's config names)
-        enc.block_trace = []
-        for _ in range(max(2, args.steps // 4)):
-            enc.forward(packed, lengths, slot=len(groups))
-        torch.cuda.synchronize()
-        blocks_full, enc.block_trace = enc.block_trace, None
+        if micro > 1:
+            enc.block_trace = []
+            for _ in range(max(2, args.steps // 4)):
+                enc.forward(packed, lengths, slot=len(groups))
+            torch.cuda.synchronize()
+            blocks_full, enc.block_trace = enc.block_trace, None
         # ... and the sub-graph alone the way the step runs it: both utterance groups' attention blocks at once, on two streams
         blocks_conc = None
         if len(groups) == 2 and not args.no_graph:
@@ -442,7 +459,7 @@ def main():
                 gblk.replay()
             e1.record()
             torch.cuda.synchronize()
-            blocks_conc = (e0.elapsed_time(e1) * 1e3 / 10 / n_calls, args.batch)
+            blocks_conc = (e0.elapsed_time(e1) * 1e3 / 10 / n_calls, len(groups[0][1]) + len(groups[1][1]))
 
     # Step decomposition in the regime that is timed: the recorded command lists of the two utterance groups, filtered to ONE
     # class of kernels (GEMMs / attention / everything else), captured as the same two-branch hipGraph and replayed.  The per-class
@@ -490,7 +507,7 @@ def main():
         e2e = end_to_end_leg(args, enc, geo, whisper, args.e2e_files, num_samples, world, D)
 
     if rank == 0:
-        total_utts = args.batch * reps * args.steps * world
+        total_utts = args.batch * inflight * reps * args.steps * world
         value = total_utts / elapsed
         gf_utt = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
         dtype_name = {"bf16": "bf16", "fp32x": "bf16x3 (fp32-grade split)", "f16": "f16 (fp32x stem)",
@@ -504,12 +521,15 @@ def main():
             "dtype": dtype_name[args.mode], "data": "synthetic",
             "config": {"workload": f"{geo.name} embed extract, batch={args.batch} x {args.seconds:.0f} s @16 kHz per GPU, "
                                    f"all {geo.num_layers + 1} hidden states to HBM, mode={args.mode}; a counted step = "
-                                   f"{reps} such batches back to back ({args.batch * reps} utterances per GPU)",
-                       "batch": args.batch, "batches_per_step": reps, "ms_per_batch": round(1e3 * elapsed / args.steps / reps, 3),
+                                   f"{reps * inflight} such batches ({args.batch * reps * inflight} utterances per GPU), "
+                                   f"{inflight} in flight at a time",
+                       "batch": args.batch, "batches_per_step": reps * inflight, "batches_in_flight": inflight,
+                       "ms_per_batch": round(1e3 * elapsed / args.steps / reps / inflight, 3),
                        "frames_per_utt": geo.max_source_positions if whisper else geo.frames_for(num_samples), "gflop_per_utt": round(gf_utt, 1),
                        "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
             "achieved_tflops_whole_path": round(value * gf_utt / 1e3 / world, 1),
-            "launch": "eager" if args.no_graph else f"hipGraph replay, {micro} concurrent utterance group(s) of {per}",
+            "launch": "eager" if args.no_graph else f"hipGraph replay, {len(branches)} concurrent branch(es): {inflight} batch(es) in flight x "
+                                                    f"{micro} utterance group(s) of {per}",
             "weight_broadcast_s": round(bcast_s, 4),
         }
         if trace:
@@ -518,7 +538,7 @@ def main():
             algo_bytes = sum(t[3] for t in trace)
             # HBM bytes per launch: only from a PMC summary taken with THESE kernel sources on THIS workload
             traffic, traffic_note = None, "no rocprofv3 PMC summary for these kernel sources / this workload under profiles/"
-            key = f"{geo.name}|{args.mode}|batch={args.batch}x{args.seconds:.0f}s|groups={micro}"
+            key = f"{geo.name}|{args.mode}|batch={args.batch}x{args.seconds:.0f}s|inflight={inflight}|groups={micro}"
             for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
                 if fn.endswith("pmc_traffic.json"):
                     rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
@@ -539,7 +559,7 @@ def main():
                 "launches": n, "avg_launch_us": round(1e3 * dur_ms / n, 2),
                 "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
                 "mfma_products_per_algorithmic_flop": mult,
-                "gemm_ms_per_batch": round(dur_ms / args.steps, 3),
+                "gemm_ms_per_batch": round(dur_ms / args.steps / inflight, 3),
                 "under_step_concurrency": None,
                 "measured": "HIP events around every ser_gemm launch, eager pass of K batches right after the timed region "
                             "(one launch at a time: no concurrent utterance group)",
@@ -548,7 +568,10 @@ def main():
                               "pipe at that clock; not measured in this run",
             }
         if decomp:
-            ms_batch = 1e3 * elapsed / args.steps / reps
+            ms_batch = 1e3 * elapsed / args.steps / reps / inflight
+            for v in decomp.values():                                  # a replay covers `inflight` batches
+                v["ms_per_batch"] = round(v["ms_per_batch"] / inflight, 4)
+                v["launches_per_batch"] //= inflight
             total = sum(v["ms_per_batch"] for v in decomp.values())
             out["step_decomposition"] = {
                 "classes": decomp, "sum_ms_per_batch": round(total, 4), "measured_ms_per_batch": round(ms_batch, 4),
@@ -558,13 +581,13 @@ def main():
                             "the other classes between its launches, so the sum can differ from the step by what cross-class overlap or "
                             "dependency bubbles are worth"}
             if trace and "roofline" in out:
-                gflop_batch = sum(t[2] for t in trace) / args.steps / 1e9
+                gflop_batch = sum(t[2] for t in trace) / args.steps / inflight / 1e9
                 ach_c = gflop_batch / decomp["gemm"]["ms_per_batch"]          # GF per ms = TF/s
                 out["roofline"]["under_step_concurrency"] = {
                     "achieved": round(ach_c, 1), "frac": round(ach_c / MFMA_BF16_PEAK_TFLOPS, 4), "unit": "TFLOP/s",
                     "gemm_ms_per_batch": decomp["gemm"]["ms_per_batch"],
-                    "measured": "the same ser_gemm launches as two concurrent utterance groups (GEMM-only command lists on the two "
-                                "branches of one hipGraph): algorithmic FLOPs of a batch / replay time"}
+                    "measured": "the same ser_gemm launches as the step's concurrent branches (GEMM-only command lists on the branches "
+                                "of one hipGraph): algorithmic FLOPs of a batch / replay time per batch"}
         if blocks:
             T = geo.frames_for(num_samples)
             Dm, dh = geo.hidden, geo.head_dim
@@ -592,12 +615,12 @@ def main():
                     "utterances_per_layer_call": utts_c, "us_per_layer_call": round(us_c, 2), "achieved": round(ach_c, 1),
                     "frac": round(ach_c / MFMA_BF16_PEAK_TFLOPS, 4),
                     "measured": "the sub-graph alone (no FFN between the blocks) captured like the timed step: one hipGraph with one "
-                                "branch per 8-utterance group, HIP events around 10 replays of all layers"}
+                                "branch per concurrent group / batch, HIP events around 10 replays of all layers"}
 
         # ---- parity_mode: throughput + measured errors of the mode that meets north_star's 1e-3 (rank 0, N = 1)
         checks_ok = verification is not None and verification["graph_replay_equals_eager_bitwise"] and verification["all_finite"]
         if world == 1 and not args.no_parity and verification is not None:
-            first = [a for a, _ in spans]                                 # first utterance of every group
+            first = [f"batch {j} utterance {a}" for j, a, _ in branches]     # first utterance of every branch
             ref = oracle_states(geo, sd, waves[0], whisper)               # CPU oracle on utterance 0 (full geometry, T frames)
             err_m = max(rel_err(hs_timed[0].utterance(0, l).cpu(), r) for l, r in enumerate(ref))
             bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3, "f16q": 1e-3, "f16a": 1e-3}[args.mode]
@@ -619,12 +642,12 @@ def main():
                     grp_p = make_groups(enc_p)
                     torch.cuda.synchronize()
                     el_p, hs_p = timed(enc_p, grp_p)
-                err_mode = max(states_err(hs_timed[g], 0, hs_p[g], 0) for g in range(len(spans)))
+                err_mode = max(states_err(hs_timed[g], 0, hs_p[g], 0) for g in range(len(branches)))
                 err_p = max(rel_err(hs_p[0].utterance(0, l).cpu(), r) for l, r in enumerate(ref))
                 out["parity_mode" if idx == 0 else f"parity_mode_{pmode}"] = {
                     "mode": pmode, "arithmetic": what[pmode],
-                    "value": round(args.batch * reps * args.steps / el_p, 2), "unit": "utterances/s",
-                    "ms_per_batch": round(1e3 * el_p / args.steps / reps, 3),
+                    "value": round(args.batch * inflight * reps * args.steps / el_p, 2), "unit": "utterances/s",
+                    "ms_per_batch": round(1e3 * el_p / args.steps / reps / inflight, 3),
                     "max_rel_err_vs_oracle": float(f"{err_p:.3e}"), "tolerance": 1e-3, "within_tolerance": bool(err_p <= 1e-3),
                     "timed_mode_max_rel_err_vs_this_mode": float(f"{err_mode:.3e}"),
                     "oracle_sample": f"utterance 0 ({args.seconds:.0f} s, all {geo.num_layers + 1} states, {ref[0].shape[0]} frames), fp32 PyTorch-CPU oracle",

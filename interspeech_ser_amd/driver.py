@@ -229,8 +229,8 @@ class _NoDist:
     driver behaves as a single process -- no sharding, no collective, the caller's process group is left alone."""
     @staticmethod
     def env():
-        from . import dist as D
-        return 0, 1, D.env()[2]
+        # "local rank" = the device the caller is already on (bench.py picked it; in a one-GPU gloo rehearsal LOCAL_RANK > 0 is no device)
+        return 0, 1, (torch.cuda.current_device() if torch.cuda.is_available() else 0)
     init = staticmethod(lambda *a, **k: None)
     shutdown = staticmethod(lambda: None)
     broadcast_int = staticmethod(lambda v, *a, **k: int(v))

@@ -25,7 +25,7 @@ PMC="--steps 2 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS"
 if [ "$2" = "traffic" ]; then   # only the two traffic passes: re-stamp profiles/<tag>_pmc_traffic.json after a kernel-source change
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
-    python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|groups=2"
+    python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|inflight=2|groups=1"
     mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_pmc_* gpurun_out/profiles_$TAG/
     echo done; exit 0
 fi
@@ -37,7 +37,7 @@ stats whisper_large_v3_bf16 --steps 3 --reps 4 --ssl_type openai/whisper-large-v
 # PMC passes: eager launches (counters are per dispatch), headline workload
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
-python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|groups=2"
+python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|inflight=2|groups=1"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_sq.err || exit 1
 python3 tools/pmc_sq_summary.py $OUT/pmc_sq profiles/$TAG
@@ -47,6 +47,6 @@ python3 tools/pmc_l2_summary.py $OUT/pmc_l2 profiles/$TAG
 WPMC="--steps 1 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS --ssl_type openai/whisper-large-v3 --seconds 30"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_fetch -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_write -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_write.err || exit 1
-python3 tools/pmc_summary.py $OUT/wpmc_fetch $OUT/wpmc_write profiles/${TAG}_whisper "openai/whisper-large-v3|bf16|batch=16x30s|groups=2"
+python3 tools/pmc_summary.py $OUT/wpmc_fetch $OUT/wpmc_write profiles/${TAG}_whisper "openai/whisper-large-v3|bf16|batch=16x30s|inflight=2|groups=1"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/      # profiles/ itself does not travel back
 echo done
