@@ -26,6 +26,7 @@
 #include "ser_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 
 #define ABQ 128      // query rows per 4-wave block (an 8-wave block takes 256)
 #define ABKV 64      // keys per tile
@@ -86,7 +87,11 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 #define SER_ATTN_MINW 2          // waves per SIMD the register allocation must leave room for (A/B knob at build time)
 #endif
 // B2D: dense additive bias from global memory instead of the relative-position table (needs PRE, excludes TBL).
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false>
+// GB: the relative-position table is read from GLOBAL memory (L2: 2T-1 floats per head) instead of an LDS window -- the form for
+// utterances whose window (T + 192 distances x 4 shifted copies) does not fit the 160 KiB of LDS (beyond ~2 min of audio): the
+// reference has no length limit (preprocess_speech.py:47-50 runs whatever librosa.load returns).  Needs PRE and TBL, head dim <= 64.
+struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };       // 16-byte load from a 4-byte aligned address
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && mode_traits<MODE>::planes == 2) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2)))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
@@ -218,7 +223,7 @@ void attention_kernel(const AttnParams p) {
                 *(f32x4*)(ldsB + c * p.bias_stride + j4) = (f32x4){bw[c], bw[c + 1], bw[c + 2], bw[c + 3]};
         }
     };
-    if (TBL) {
+    if (TBL && !GB) {
         // only the distances this block's queries can see: key - query + T-1 in [jmin, jmin + 32*NWV + T + 63]
         trow = p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T) + jmin;
         bn = 2 * T - 1 - jmin;
@@ -259,7 +264,7 @@ void attention_kernel(const AttnParams p) {
 
     DBG_P(2);
     // ---- this head's bias row, 4 shifted copies: copy c [j] = table[h][(table_T-T) + jmin + j + c] -------
-    if (TBL) {
+    if (TBL && !GB) {
         bias_write(4 * tid);
         for (int j4 = 4 * (tid + NT); j4 < p.bias_stride; j4 += 4 * NT) {   // utterances beyond ~8 s: further passes
             bias_load(j4);
@@ -283,6 +288,22 @@ void attention_kernel(const AttnParams p) {
     // aligned bias window: index of key kb (multiple of 4) is kb - qc + T-1 - jmin = a + sh with a % 4 == 0
     const int bsh = (T - 1 - qc - jmin) & 3;
     const float* bcopy = ldsB + bsh * p.bias_stride + ((T - 1 - qc - jmin) - bsh);
+    // GB: this query's row of distances in the global table: gbias[k] = table[h][k - q + T-1 (+ table_T - T)], k = key index
+    const float* gbias = GB ? p.table + (int64_t)h * (2 * p.table_T - 1) + (p.table_T - T) + (T - 1 - qc) : nullptr;
+    auto bias_quad = [&](int kb, bool ragged) -> f32x4 {          // gate-less bias of keys kb..kb+3 for this lane's query
+        if constexpr (GB) {
+            if (!ragged) {
+                const f32x4_u u = *(const f32x4_u*)(gbias + kb);
+                return (f32x4){u.v[0], u.v[1], u.v[2], u.v[3]};
+            }
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (kb + e < T) ? gbias[kb + e] : 0.f;      // never past the utterance's own distances
+            return r;
+        } else {
+            return *(const f32x4*)(bcopy + kb);
+        }
+    };
 
     f32x16 ot[DSUB];
 #pragma unroll
@@ -330,7 +351,7 @@ void attention_kernel(const AttnParams p) {
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
-                        bvv[sub][g4] = *(const f32x4*)(bcopy + kt * ABKV + sub * 32 + 8 * g4 + 4 * hh);
+                        bvv[sub][g4] = bias_quad(kt * ABKV + sub * 32 + 8 * g4 + 4 * hh, RAGGED);
             }
             if (PRE && B2D) {                                        // rows are b2d_ld = a multiple of 64 floats long, zero padded
 #pragma unroll
@@ -365,7 +386,7 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
-                        const f32x4 bv = *(const f32x4*)(bcopy + kb);
+                        const f32x4 bv = bias_quad(kb, RAGGED);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = gq2 * bv[r];
                     }
@@ -548,14 +569,14 @@ void attention_kernel(const AttnParams p) {
     }
 }
 
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false>
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D>;
-    static bool ready = false;
-    if (lds > 65536 && !ready) {
+    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D, GB>;
+    static std::atomic<bool> ready{false};          // several host threads launch (see gemm.hip launch_mode)
+    if (lds > 65536 && !ready.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return ser_fail((int)e, "ser_attention: cannot raise dynamic LDS");
-        ready = true;
+        ready.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(k, grid, dim3(64 * NWV), lds, s, p);
     return ser_check_launch("ser_attention");
@@ -598,7 +619,11 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
         bias_stride = ((max_frames + 32 * nwv + 2 * ABKV + 3 + 4) / 4) * 4;   // window of one query block (+ the 0..3 alignment slots), not all 2T-1 distances
         bias_stride += (16 - (bias_stride & 63) + 64) & 63;
     }
-    const size_t lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
+    size_t lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
+    // a bias window that does not fit (utterances beyond ~2 min; ~1.5 min in the two-plane modes): the table is read from global
+    // memory instead (GB forms: pre-scaled q, head dim <= 64 -- what the WavLM encoders use)
+    const bool gbias = table && lds > 160 * 1024 && scale <= 0.f && dhp == 64 && nwv == 4;
+    if (gbias) { bias_stride = 0; lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2; }
     if (lds > 160 * 1024) return ser_fail(-8, "ser_attention: LDS need %zu > 160 KiB (max_frames=%d)", lds, max_frames);
     AttnParams p;
     p.qkv = (const unsigned short*)qkv; p.ld = ld; p.plane = plane_stride;
@@ -617,6 +642,15 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     const bool pre = scale <= 0.f;
 #define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
                               : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
+    if (gbias) {
+        switch (mode) {
+            case SER_MODE_BF16:  return launch_attention<64, SER_MODE_BF16, true, true, 4, false, true>(p, grid, lds, s);
+            case SER_MODE_FP16:  return launch_attention<64, SER_MODE_FP16, true, true, 4, false, true>(p, grid, lds, s);
+            case SER_MODE_FP32X: return launch_attention<64, SER_MODE_FP32X, true, true, 4, false, true>(p, grid, lds, s);
+            case SER_MODE_FP16X: return launch_attention<64, SER_MODE_FP16X, true, true, 4, false, true>(p, grid, lds, s);
+            default:             return launch_attention<64, SER_MODE_FP16Q, true, true, 4, false, true>(p, grid, lds, s);
+        }
+    }
     if (bias2d)
         return mode == SER_MODE_FP32X ? launch_attention<64, SER_MODE_FP32X, true, false, 4, true>(p, grid, lds, s)
                                       : launch_attention<64, SER_MODE_BF16, true, false, 4, true>(p, grid, lds, s);

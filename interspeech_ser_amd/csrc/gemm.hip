@@ -29,6 +29,7 @@
 #endif
 #include <stdlib.h>
 #include <stdio.h>
+#include <atomic>
 #ifdef SER_GEMM_DBG
 // diagnostic build only (tools/gemm_clock.py): wave 0 of every block stamps s_memtime / s_memrealtime around its K loop
 extern "C" { void* ser_gemm_dbg_ptr = nullptr; }
@@ -660,11 +661,13 @@ enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN5
 template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
 static hipError_t launch_mode(const ser_gemm_args* a, dim3 grid, dim3 block, int LDS, hipStream_t s) {
     auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, MODE, LNEPI, OM>;
-    static bool ready = false;                     // per instantiation; benign race (idempotent call)
-    if (LDS > 65536 && !ready) {
+    // per instantiation; the drivers launch from several host threads: an atomic flag (two threads may both make the
+    // idempotent call, neither reads a half-written flag)
+    static std::atomic<bool> ready{false};
+    if (LDS > 65536 && !ready.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        ready = true;
+        ready.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(k, grid, block, LDS, s, *a);
     return hipSuccess;

@@ -52,9 +52,9 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
                    help="fp32x: fp32-grade results everywhere (~2e-5 of the fp32 reference); f16a: fp32-grade conv stem and "
                         "attention blocks, single-product fp16 feed-forward (within 1e-3 on every stress fixture); f16q: only the "
                         "attention-logit path (q / k projection, QK^T) fp32-grade; f16: fp16 layers throughout (within 1e-3 on "
-                        "Gaussian weights, 3-5e-3 under sharp attention); bf16: fastest (~1e-2).  Limits: WavLM utterances up "
-                        "to ~2 min (the relative-position bias window of one utterance must fit the 160 KiB LDS; longer "
-                        "files are reported per file and skipped), utterances of at least 400 samples")
+                        "Gaussian weights, 3-5e-3 under sharp attention); bf16: fastest (~1e-2).  Limits: utterances of at least 400 "
+                        "samples (the conv stack's receptive field); no upper limit (WavLM utterances beyond ~2 min read their "
+                        "relative-position bias from global memory instead of LDS)")
     p.add_argument("--checkpoint", type=str, default="",
                    help="local *.safetensors / pytorch_model.bin (or directory); default: HF cache lookup, "
                         "else seeded synthetic weights")

@@ -38,3 +38,32 @@ def built_library():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def write_tiny_roberta_tokenizer(path):
+    """A RobertaTokenizer that loads OFFLINE: byte-level vocab.json (4 specials + the 256 byte symbols + a few merges + <mask>,
+    266 entries: fits the tiny RoBERTa fixture geometry's 300-row embedding) and merges.txt, in the layout
+    ``RobertaTokenizer.from_pretrained(dir, local_files_only=True)`` reads -- the call the text drivers make
+    (driver.hf_tokenize_fn; reference: preprocessing/preprocess_roberta.py:48-54).  The hub's real vocabulary cannot be fetched here."""
+    import json
+    os.makedirs(path, exist_ok=True)
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAC + 1)) + list(range(0xAE, 0xFF + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    for c in cs:
+        vocab[chr(c)] = len(vocab)
+    merges = ["\u0120 t", "h e", "\u0120t he", "a n", "\u0120 a"]
+    for m in merges:
+        vocab["".join(m.split())] = len(vocab)
+    vocab["<mask>"] = len(vocab)
+    with open(os.path.join(path, "vocab.json"), "w", encoding="utf-8") as f:
+        json.dump(vocab, f, ensure_ascii=False)
+    with open(os.path.join(path, "merges.txt"), "w", encoding="utf-8") as f:
+        f.write("#version: 0.2\n" + "\n".join(merges) + "\n")
+    return path

@@ -176,6 +176,32 @@ def test_extreme_ragged_batch_matches_oracle():
     assert worst < 1e-3, worst
 
 
+@pytest.mark.parametrize("mode", ["fp32x", "f16a"])
+def test_three_minute_utterance_has_no_length_limit(mode):
+    """A 3 min clip (8 999 frames) next to a 1 s one, tiny WavLM geometry, against the CPU oracle: the relative-position
+    window of such an utterance does not fit LDS, so attention reads the bias table from global memory (csrc/attention.hip, GB form).
+    The reference imposes no limit (preprocess_speech.py:47-50); rounds 1-2 logged and skipped files beyond ~2 min."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.TINY_WAVLM
+    sd = synthetic_state_dict(geo, 31)
+    waves = [synth_wave(77, 180 * 16000), synth_wave(78, 16000)]
+    enc = SpeechEncoder(geo, sd, "cuda:0", mode=mode)
+    hs = enc.forward(enc.upload(waves), [len(w) for w in waves])
+    torch.cuda.synchronize()
+    assert hs.frames(0) == geo.frames_for(180 * 16000) == 8999
+    worst = 0.0
+    for b, w in enumerate(waves):
+        with torch.no_grad():
+            ref = O.speech_hidden_states(geo, sd, torch.from_numpy(O.zero_mean_unit_var(w)))
+        for layer, r in enumerate(ref):
+            worst = max(worst, rel_err(hs.utterance(b, layer).cpu(), r))
+    print(f"3 min utterance, {mode}: worst rel err {worst:.3e}")
+    assert worst < 1e-3, worst
+
+
 def test_too_short_utterance_is_rejected_cleanly():
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import SpeechEncoder
@@ -310,6 +336,42 @@ def test_roberta_driver_files(tmp_path, capsys):
     with torch.no_grad():
         ref = O.roberta_hidden_states(geo, sd, ids[0], mask[0])[-1]
     assert rel_err(got, ref) < 1e-3
+
+
+def test_roberta_driver_with_the_reference_tokenizer_call(tmp_path, capsys):
+    """The text driver's DEFAULT tokenizer path -- HF RobertaTokenizer.from_pretrained(<local files>) called like the reference does
+    (preprocess_roberta.py:45-54: padding="max_length", truncation=True, max_length=80) -- end to end through ``--tokenizer_path``:
+    no injected stand-in.  Vocabulary files: the offline byte-level set of tests/conftest.py (266 entries, so the tiny RoBERTa
+    geometry's 300-row table holds every id); the features equal the oracle's on the ids that tokenizer produces."""
+    pytest.importorskip("transformers")
+    import pandas as pd
+    from conftest import write_tiny_roberta_tokenizer
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    tok_dir = write_tiny_roberta_tokenizer(str(tmp_path / "tok"))
+    texts = ["the cat and the hat", "hm", "a much longer sentence than the others, with punctuation!"]
+    pd.DataFrame({"FileName": ["a_0001.wav", "b_0002.wav", "c_0003.wav"], "transcription": texts}).to_csv(tmp_path / "t.csv", index=False)
+    out = tmp_path / "feats"
+    C._REGISTRY["tiny-roberta-test"] = C.TINY_ROBERTA
+    try:
+        rc = driver.run_roberta(["--roberta_type", "tiny-roberta-test", "--df_path", str(tmp_path / "t.csv"), "--save_path", str(out),
+                                 "--synthetic_weights", "--max_len", "80", "--tokenizer_path", tok_dir])
+    finally:
+        C._REGISTRY.pop("tiny-roberta-test")
+    assert rc == 0, capsys.readouterr().out
+    assert sorted(os.listdir(out)) == ["a_0001.pt", "b_0002.pt", "c_0003.pt"]
+    geo = C.TINY_ROBERTA
+    sd = synthetic_state_dict(geo, 7)
+    ids, mask = driver.hf_tokenize_fn(tok_dir, 80)(texts)
+    assert int(mask[1].sum()) == 4 and int(mask[2].sum()) > 20
+    for j, name in enumerate(("a_0001", "b_0002", "c_0003")):
+        got = torch.load(out / f"{name}.pt")
+        assert tuple(got.shape) == (80, geo.hidden)
+        with torch.no_grad():
+            ref = O.roberta_hidden_states(geo, sd, ids[j], mask[j])[-1]
+        assert rel_err(got, ref) < 1e-3
 
 
 @pytest.mark.parametrize("model", ["microsoft/deberta-v3-large", "microsoft/deberta-v2-xlarge"])

@@ -616,6 +616,48 @@ def test_attention_long_utterance_bias_window(L, mode):
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
+def test_attention_unbounded_utterance_reads_the_table_from_global_memory(L, mode):
+    """The reference has no utterance-length limit (preprocess_speech.py:47-50).  An utterance whose relative-position window no
+    longer fits the 160 KiB of LDS (8 200 frames = 164 s here; the LDS form stops at ~5 900-7 900 depending on the mode) takes the
+    kernel form that reads the [H, 2T-1] table from global memory; a short utterance in the same ragged batch shares the launch.
+    q pre-scaled (the host always does), fused gate columns.  Reference in fp64, queries in chunks."""
+    Ts, H, dh = [8200, 150], 1, 64
+    D, M, Tmax = H * dh, sum(Ts), max(Ts)
+    g = torch.Generator().manual_seed(8200)
+    ld = 3 * D + 8
+    qkv = torch.randn(M, ld, generator=g)
+    c = dh ** -0.5 * 1.4426950408889634
+    pre = qkv.clone()
+    pre[:, :D] *= c
+    qa = to_act(pre, mode)
+    qv = act_value(qa).cpu().double()
+    table = torch.randn(H, 2 * Tmax - 1, generator=g)
+    cst = torch.randn(H, generator=g) + 1.0
+    pg = qv[:, 3 * D: 3 * D + 2 * H].view(M, H, 2)
+    gate = torch.sigmoid(pg[..., 0]) * (torch.sigmoid(pg[..., 1]) * cst.double()[None, :] - 1.0) + 2.0
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    ref = torch.empty(M, D, dtype=torch.float64)
+    for b, T in enumerate(Ts):
+        sl = slice(offs[b], offs[b + 1])
+        q, k, v = qv[sl, :D] / c, qv[sl, D:2 * D], qv[sl, 2 * D:3 * D]
+        tb = table[0, Tmax - 1 - (T - 1): Tmax - 1 + T].double()
+        for q0 in range(0, T, 1024):
+            q1 = min(T, q0 + 1024)
+            idx = (torch.arange(T)[None, :] - torch.arange(q0, q1)[:, None]) + (T - 1)
+            sc = (q[q0:q1] @ k.T) * dh ** -0.5 + gate[sl][q0:q1, 0:1] * tb[idx]
+            ref[offs[b] + q0: offs[b] + q1] = torch.softmax(sc, dim=-1) @ v
+    planes = 2 if mode == 2 else 1
+    out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    td, cd = table.to(DEV), cst.to(DEV)
+    L.check(L.lib.ser_attention(qa.data_ptr(), ld, M * ld, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax, td.data_ptr(), Tmax,
+                                None, out.data_ptr(), D, M * D, H, dh, -1.0, mode, 3 * D, cd.data_ptr(), None, None, 0, stream()))
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < mode_tol(mode, 3e-2, 1e-4), err
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_attention_fused_gate_columns(L, mode):
     """WavLM gate from its two pre-activation columns per head inside the packed projection matrix."""
     Ts, H, dh = [90, 200], 2, 64

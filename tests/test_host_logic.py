@@ -100,6 +100,24 @@ def test_geometry_from_config_json(tmp_path):
     assert C.resolve_geometry("microsoft/wavlm-large") is C.WAVLM_LARGE      # table fallback
 
 
+def test_text_driver_tokenizer_call_with_local_files(tmp_path):
+    """The text drivers' default tokenizer path (driver.hf_tokenize_fn = the reference's
+    ``RobertaTokenizer.from_pretrained(...)(text, padding="max_length", truncation=True, max_length=L)``,
+    preprocess_roberta.py:45-54) with vocabulary files on disk and no network: [n, L] ids, right padding with <pad> = 1,
+    truncation at L; a missing directory is the OSError the driver reports as "No pretrained model found"."""
+    pytest.importorskip("transformers")
+    from conftest import write_tiny_roberta_tokenizer
+    d = write_tiny_roberta_tokenizer(str(tmp_path / "tok"))
+    fn = driver.hf_tokenize_fn(d, 16)
+    ids, mask = fn(["the cat and the hat", "hm", "x " * 40])
+    assert tuple(ids.shape) == tuple(mask.shape) == (3, 16)
+    assert int(ids[0, 0]) == 0 and int(ids[1, 3]) == 2 and ids[1, 4:].eq(1).all() and mask[1].tolist() == [1] * 4 + [0] * 12
+    assert mask[2].all() and int(ids[2, -1]) == 2                        # truncated to 16 with </s> kept
+    assert int(ids.max()) < 300                                          # fits the tiny fixture geometry's embedding table
+    with pytest.raises(OSError):
+        driver.hf_tokenize_fn(str(tmp_path / "nowhere"), 16)
+
+
 def test_deberta_v2_xlarge_geometry_is_registered():
     """The checkpoint the reference's README names for preprocess_deroberta.py (README.md:66): 24 x 1536, 24 heads of 64,
     ConvLayer with kernel 3; 884.6 M parameters with HF's DebertaV2Model at these values."""
