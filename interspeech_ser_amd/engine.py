@@ -48,9 +48,10 @@ _DTYPE = {_lib.MODE_BF16: torch.bfloat16, _lib.MODE_FP32X: torch.bfloat16, _lib.
 # A/B knob (tools/): SER_NO_SHIFT=1 turns the shifted operand copy of the encoder layers off (state 0 is still centred)
 import os as _os
 _NO_SHIFT = _os.environ.get("SER_NO_SHIFT", "0") == "1"
-# A/B knob (tools/): SER_SPLIT_GATE=0 keeps WavLM's 2H gate columns inside the packed QKV launch (N = 3D + 32: a 13th column tile of 256
-# for 32 columns); default 1 = their own small launch, so the packed projection is exactly 12 tiles wide
-_SPLIT_GATE = _os.environ.get("SER_SPLIT_GATE", "1") == "1"
+# A/B knob (tools/): SER_SPLIT_GATE=1 gives WavLM's 2H gate columns their own small launch so that the packed projection is exactly
+# 12 column tiles of 256 wide instead of 13 (N = 3D + 32).  Measured (round 3, two A/B pairs): bf16 1 941 / 1 940 -> 1 933 / 1 937 utt/s,
+# f16a 1 103 -> 1 098: the extra launch (its own deferred-LayerNorm prologue, 63 blocks) costs what the 13th tile column does.  Default 0.
+_SPLIT_GATE = _os.environ.get("SER_SPLIT_GATE", "0") == "1"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
