@@ -30,7 +30,7 @@ if [ "$2" = "traffic" ]; then   # only the two traffic passes: re-stamp profiles
     echo done; exit 0
 fi
 stats wavlm_large_bf16 --steps 10 || exit 1
-stats wavlm_large_f16 --steps 10 --mode f16 || exit 1
+stats wavlm_large_f16a --steps 10 --mode f16a || exit 1
 stats hubert_xlarge_bf16 --steps 5 --ssl_type facebook/hubert-xlarge-ll60k || exit 1
 stats xlsr_2b_bf16 --steps 5 --ssl_type facebook/wav2vec2-xls-r-2b --batch 8 || exit 1
 stats whisper_large_v3_bf16 --steps 3 --reps 4 --ssl_type openai/whisper-large-v3 --seconds 30 || exit 1
@@ -47,6 +47,6 @@ python3 tools/pmc_l2_summary.py $OUT/pmc_l2 profiles/$TAG
 WPMC="--steps 1 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS --ssl_type openai/whisper-large-v3 --seconds 30"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_fetch -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_write -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_write.err || exit 1
-python3 tools/pmc_summary.py $OUT/wpmc_fetch $OUT/wpmc_write profiles/${TAG}_whisper "openai/whisper-large-v3|bf16|batch=16x30s|inflight=2|groups=1"
+python3 tools/pmc_summary.py $OUT/wpmc_fetch $OUT/wpmc_write profiles/${TAG}_whisper "openai/whisper-large-v3|bf16|batch=16x30s|inflight=1|groups=2"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/      # profiles/ itself does not travel back
 echo done
