@@ -85,6 +85,52 @@ def test_speech_driver_config0(tmp_path, capsys):
         assert float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
 
 
+def test_unknown_hub_name_resolves_through_the_snapshot_config_json(tmp_path, capsys, monkeypatch):
+    """a3: ``AutoModel.from_pretrained(--ssl_type)`` works for any hub id because the snapshot carries its own config.json
+    (preprocess_speech.py:111-112).  A fine-tune under a name the built-in table does not know -- offline HF cache layout
+    ``$HF_HOME/hub/models--acme--wavlm-ser-v7/snapshots/<rev>/{config.json, model.safetensors}``, keys with the ``wavlm.`` prefix a
+    task-head checkpoint has -- runs through the speech driver with the README's command line (no --checkpoint, no
+    --synthetic_weights), and so does the same directory given as --ssl_type; a GroupNorm variant is refused with the reference's line."""
+    import json
+    from safetensors.torch import save_file
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.frontend import load_wav_16k
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.TINY_WAVLM
+    sd = synthetic_state_dict(geo, 77)
+    cfg = {"model_type": "wavlm", "hidden_size": geo.hidden, "num_hidden_layers": geo.num_layers, "num_attention_heads": geo.heads,
+           "intermediate_size": geo.ffn, "conv_dim": list(geo.conv_dim), "conv_kernel": list(geo.conv_kernel),
+           "conv_stride": list(geo.conv_stride), "conv_bias": geo.conv_bias, "feat_extract_norm": "layer", "do_stable_layer_norm": True,
+           "num_conv_pos_embeddings": geo.pos_conv_kernel, "num_conv_pos_embedding_groups": geo.pos_conv_groups,
+           "num_buckets": geo.num_buckets, "max_bucket_distance": geo.max_bucket_distance, "layer_norm_eps": geo.layer_norm_eps}
+    snap = tmp_path / "hf" / "hub" / "models--acme--wavlm-ser-v7" / "snapshots" / "0123abcd"
+    snap.mkdir(parents=True)
+    (snap / "config.json").write_text(json.dumps(cfg))
+    save_file({"wavlm." + k: v.contiguous() for k, v in sd.items()}, str(snap / "model.safetensors"))
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    write_wav(wav_dir / "a.wav", synth(5, 16000))
+    write_wav(wav_dir / "b.wav", synth(6, 9000))
+    for tag, ssl_type in (("cache", "acme/wavlm-ser-v7"), ("dir", str(snap))):
+        out = tmp_path / f"pt_{tag}"
+        rc = driver.run_speech(["--ssl_type", ssl_type, "--wav_dir", str(wav_dir), "--save_path", str(out), "--mode", "fp32x"])
+        text = capsys.readouterr().out
+        assert rc == 0 and "No pretrained model found" not in text, text
+        assert sorted(os.listdir(out)) == ["a.pt", "b.pt"]
+        x = load_wav_16k(str(wav_dir / "b.wav"))
+        ref = O.extract_speech(geo, sd, x, layer_index=0)                 # fresh directory -> hidden_states[0] (the reference's rule)
+        got = torch.load(out / "b.pt")
+        assert got.shape == ref.shape and float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))) < 1e-3
+    cfg["feat_extract_norm"] = "group"
+    (snap / "config.json").write_text(json.dumps(cfg))
+    rc = driver.run_speech(["--ssl_type", "acme/wavlm-ser-v7", "--wav_dir", str(wav_dir), "--save_path", str(tmp_path / "pt_bad")])
+    text = capsys.readouterr().out
+    assert rc == 0 and "No pretrained model found with the name acme/wavlm-ser-v7" in text and "GroupNorm" in text
+
+
 def test_early_exit_states_are_bit_equal_to_the_full_forward():
     """``last_state`` = N launches only what hidden_states[0..N] need (the reference keeps one state per utterance,
     preprocess_speech.py:67 / preprocess_whisper.py:71): the states it leaves are bit-equal to the full forward's, through

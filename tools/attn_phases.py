@@ -12,11 +12,14 @@ from interspeech_ser_amd import _lib as L
 DEV = "cuda:0"; st = torch.cuda.current_stream().cuda_stream
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 499
 bias = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # 1 bf16, 3 fp16, 5 fp16q, 4 fp16x, 2 fp32x (two-plane modes need scale <= 0)
+PL = 2 if MODE in (2, 4, 5) else 1
+DT = torch.bfloat16 if MODE in (1, 2) else torch.float16
 B, H, dh = 8, 16, 64
 D = H * dh
 M = B * T
-qkv = torch.randn(1, M, 3 * D, device=DEV).to(torch.bfloat16)
-out = torch.empty(1, M, D, dtype=torch.bfloat16, device=DEV)
+qkv = torch.randn(PL, M, 3 * D, device=DEV).to(DT)
+out = torch.empty(PL, M, D, dtype=DT, device=DEV)
 offs = torch.arange(0, M + 1, T, dtype=torch.int32, device=DEV)
 table = torch.randn(H, 2 * T - 1, device=DEV); gate = torch.rand(M, H, device=DEV)
 dbg = torch.zeros(4 * 64 * 6, dtype=torch.int64, device=DEV)
@@ -24,7 +27,7 @@ C.c_void_p.in_dll(L.lib, "ser_attn_dbg_ptr").value = dbg.data_ptr()
 def run():
     L.check(L.lib.ser_attention(qkv.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, offs.data_ptr(), B, T,
                                 table.data_ptr() if bias else None, T if bias else 0, gate.data_ptr() if bias else None,
-                                out.data_ptr(), D, M * D, H, dh, dh ** -0.5, 1, 0, None, None, None, 0, st))
+                                out.data_ptr(), D, M * D, H, dh, -1.0 if PL == 2 else dh ** -0.5, MODE, 0, None, None, None, 0, st))
 for _ in range(5): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
