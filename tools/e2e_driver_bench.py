@@ -20,6 +20,7 @@ for i in range(n):
     secs += L / 16000
 t0 = time.perf_counter()
 driver.run_speech(["--ssl_type", "microsoft/wavlm-large", "--wav_dir", wav_dir, "--save_path", out, "--synthetic_weights",
+                   "--use_n_layer", "--n_layer", "-1",        # the last state: every layer runs (the reference's default rule would stop after state 0)
                    "--mode", mode, "--batch_size", os.environ.get("BS", "16"), "--num_workers", os.environ.get("NW", "4"), "--timing"])
 dt = time.perf_counter() - t0
 print(f"E2E {n} files ({secs:.0f} s audio) incl. weight init: {dt:.1f} s; files written: {len(os.listdir(out))}")
