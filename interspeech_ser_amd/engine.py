@@ -37,7 +37,7 @@ MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16
 # projection / feed-forward stay single-product fp16.  A softmax weight moves by (logit error) * ln 2, so q / k rounding is
 # what sharp attention maps (trained checkpoints, LoRA-scaled query projections) amplify; ~19 % of the layer FLOPs pay 3x.
 # "f16a": the whole ATTENTION BLOCK of every layer (packed projection, attention, output projection) on the fp16 hi + lo split,
-# the feed-forward pair (62 % of the layer FLOPs) on single fp16 products.  tools/numerics_whatif.py: under sharp attention the
+# the feed-forward pair (62 % of the layer FLOPs) on single fp16 products.  oracle/numerics_whatif.py: under sharp attention the
 # error comes from the attention block as a whole -- rounding v, P, the context rows or the output-projection weights once is
 # amplified by the following layers' softmax as much as rounding q and k -- while the feed-forward rounding is benign.
 _PLANES = {_lib.MODE_BF16: 1, _lib.MODE_FP32X: 2, _lib.MODE_FP16: 1, _lib.MODE_FP16X: 2}

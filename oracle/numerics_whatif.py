@@ -1,7 +1,7 @@
-"""CPU what-if for the numerics modes (no GPU): the encoder layers in fp64 with fp16 OPERAND ROUNDING switched on per GEMM
+"""ANALYSIS / TEST INFRASTRUCTURE ONLY (never imported by the product).  CPU what-if for the numerics modes (no GPU): the encoder layers in fp64 with fp16 OPERAND ROUNDING switched on per GEMM
 site, so that the error of a candidate mode is known before a kernel is written (DESIGN.md section 4 records the outcomes).
 
-    python tools/numerics_whatif.py [tiny_wavlm|tiny_hubert|tiny_wav2vec2|wavlm_large] [plain|sharp|lora]
+    python oracle/numerics_whatif.py [tiny_wavlm|tiny_hubert|tiny_wav2vec2|wavlm_large] [plain|sharp|lora]
 
 Sites (what the HIP path rounds to one fp16 plane in the "f16" mode; "exact" = fp16 hi + lo planes, 3 products):
     x_qk, w_qk   operands of the q / k (+ gate) columns of the packed projection      q_k    the stored q, k (operands of S = K Q^T)
@@ -20,7 +20,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interspeech_ser_amd import config as C                              # noqa: E402
 from interspeech_ser_amd.weights import apply_stress, synthetic_state_dict  # noqa: E402
-from oracle import ssl_oracle as O                                        # noqa: E402  (tools are not product code)
+from oracle import ssl_oracle as O                                        # noqa: E402  (this file lives under oracle/: checker-side code)
 
 ALL = ("x_qk", "w_qk", "q_k", "x_v", "w_v", "v", "p", "ctx", "w_o", "h", "w_1", "ffn", "w_2")
 

@@ -1,9 +1,9 @@
-"""CPU what-if for the conv stem (no GPU): which operand of the stem GEMMs needs its second plane?  fp64 arithmetic with fp16
+"""ANALYSIS / TEST INFRASTRUCTURE ONLY (never imported by the product).  CPU what-if for the conv stem (no GPU): which operand of the stem GEMMs needs its second plane?  fp64 arithmetic with fp16
 rounding of the conv / projection / positional-conv ACTIVATION operand and / or WEIGHT operand, followed by the encoder
-layers of tools/numerics_whatif.py either exact or with the "f16a" rounding set.  Today every parity mode runs the stem on the
+layers of oracle/numerics_whatif.py either exact or with the "f16a" rounding set.  Today every parity mode runs the stem on the
 3-product split (both operands two planes); a 2-product form (one operand single-plane) would cut a third of its MFMA work.
 
-    python tools/numerics_whatif_stem.py [tiny_wavlm|wavlm_large]"""
+    python oracle/numerics_whatif_stem.py [tiny_wavlm|wavlm_large]"""
 import os
 import sys
 

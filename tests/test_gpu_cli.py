@@ -362,7 +362,7 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
     # adapters make the query projection ~4x larger than the base weights, i.e. attention logits ~4x larger, and single-product
     # operand rounding (2^-12 relative per operand) moves a softmax weight by (logit error) * ln 2: measured 2.9e-3 here against
     # 6-8e-4 on the unadapted geometries.  f16q (fp32-grade logit path only) measures 1.8e-3 / 4.0e-3: roundings of v, P, the
-    # context rows and the output projection are amplified by the NEXT layer's softmax just the same (tools/numerics_whatif.py)
+    # context rows and the output projection are amplified by the NEXT layer's softmax just the same (oracle/numerics_whatif.py)
     # -- the reason f16a (whole attention block on the 3-product split) exists.
     print(f"LoRA {family} {mode}: worst rel err {worst:.3e}")
     assert worst < (5e-3 if mode in ("f16", "f16q") else 1e-3), worst
