@@ -57,7 +57,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // WM x WN waves, each TM x TN MFMA tiles of 16x16; BK = K tile; ST = ring stages.
 // OM: format of the out_act copy (== MODE unless the launch converts, e.g. an FP32X stem GEMM feeding FP16 layers).
-template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
+// PERSIST (round 3 experiment, SER_GEMM_PERSIST=1): the launch has only as many blocks as are resident at once and each walks several tiles.
+template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WM * WN, 2)
 void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -86,7 +87,16 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 
     const int ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;
-    int bid = blockIdx.x;
+    // Tile loop.  A normal launch has one block per tile (no loop is compiled).  A PERSIST launch has as many blocks as fit the chip at
+    // once and every block walks tiles vb, vb + gridDim.x, ...; between two tiles the previous epilogue's stores are drained (gfx950 counts
+    // stores in vmcnt, and the ring below waits on COUNTED vmcnt for its LDS-DMA) and every wave has left the previous tile's LDS reads.
+    int vb = blockIdx.x;
+    do {
+    if (PERSIST && vb != (int)blockIdx.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    int bid = vb;
     {   // bijective XCD remap: blocks with equal (bid & 7) share an L2
         const int nwg = ntm * ntn;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -653,14 +663,15 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         if (d && wave == 0 && lane == 0 && blockIdx.y == 0) d[131072 + blockIdx.x * 4 + 2] = t2;
     }
 #endif
+    } while (PERSIST && (vb += gridDim.x) < ntm * ntn);   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
 enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN512_M64 = 4, CFG_LN512_M32 = 5, CFG_128x64 = 6 };
 
-template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
+template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE, bool PERSIST = false>
 static hipError_t launch_mode(const ser_gemm_args* a, dim3 grid, dim3 block, int LDS, hipStream_t s) {
-    auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, MODE, LNEPI, OM>;
+    auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, MODE, LNEPI, OM, PERSIST>;
     // per instantiation; the drivers launch from several host threads: an atomic flag (two threads may both make the
     // idempotent call, neither reads a half-written flag)
     static std::atomic<bool> ready{false};
@@ -682,6 +693,18 @@ static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     hipError_t e = hipSuccess;
+    if constexpr (!X32 && !LNEPI && BN >= 128) {
+        // SER_GEMM_PERSIST=1 (A/B knob, default 0; bf16 launches of the dense tiles only): launches with more tiles than fit the chip at once
+        // start only the resident blocks, which then walk the tiles
+        static const int persist = [] { const char* e = getenv("SER_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+        const int per_cu = LDS > 80 * 1024 ? 1 : 2;
+        if (persist && a->groups == 1 && a->mode == SER_MODE_BF16 && grid.x > 256u * per_cu) {
+            grid.x = 256u * per_cu;
+            e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_BF16, LNEPI, SER_MODE_BF16, true>(a, grid, block, LDS, s);
+            if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
+            return ser_check_launch("ser_gemm");
+        }
+    }
     if constexpr (X32) {
         if constexpr (!LNEPI) {
             if (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16)      // output projection of "f16a": 3 products, one-plane copy for FC1

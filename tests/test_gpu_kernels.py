@@ -135,6 +135,22 @@ def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
     assert torch.equal(out.cpu().double(), ref)
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_many_tiles_per_cu_integer_exact(L, cfg):
+    """Grids of several tiles per CU (3 768 / 1 896 / 948 tiles of 128x128 / 256x128 / 256x256), ragged edges, bias + residual: exact
+    integers.  tools/gemm_persist_ab.sh runs this file once more under SER_GEMM_PERSIST=1, where these launches take the persistent
+    tile-loop form of the kernel (round 3 experiment) and must give the same integers."""
+    M, N, K = 20011, 3000, 192
+    g = torch.Generator().manual_seed(cfg)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    res = torch.randint(-9, 10, (M, N), generator=g).float()
+    ref = A.double() @ W.double().T + bias.double() + res.double()
+    out, _ = run_gemm(L, to_act(A, 1), to_act(W, 1), M, N, K, 1, bias=bias.to(DEV), residual=res.to(DEV), ldr=N, tile_cfg=cfg)
+    assert torch.equal(out.cpu().double(), ref)
+
+
 def test_gemm_fp32x_large_grid_tile_integer_exact(L):
     """FP32X launches with >= 100 tiles of 256 x 128 take the 256x128 / BK = 32 / 3-stage ping-pong tile (gemm.hip, ser_gemm): ragged M
     and N edges, K = 64..320 (ring fill and drain at 2..10 K tiles), integer operands so that one misplaced fragment shows."""
