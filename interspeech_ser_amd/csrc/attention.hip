@@ -46,6 +46,7 @@ struct AttnParams {
     unsigned short* out;
     int64_t ldo, out_plane;
     int H, dh, B, nq;
+    int nitems;           // grid size of the one-block-per-item form (PERSIST blocks walk items up to it)
     int bias_stride;      // floats per shifted bias copy in LDS
     float scale;
     // dense additive bias (DeBERTa's disentangled-attention terms, built by ser_deberta_bias): [B][H][T][b2d_ld] fp32 in the
@@ -91,7 +92,9 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 // utterances whose window (T + 192 distances x 4 shifted copies) does not fit the 160 KiB of LDS (beyond ~2 min of audio): the
 // reference has no length limit (preprocess_speech.py:47-50 runs whatever librosa.load returns).  Needs PRE and TBL, head dim <= 64.
 struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };       // 16-byte load from a 4-byte aligned address
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
+// PERSIST (round 3 experiment, SER_ATTN_PERSIST=1): the launch has only the blocks that are resident at once (two per CU) and each walks
+// (utterance, head, q-tile) items L, L + gridDim.x, ...
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false, bool PERSIST = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && mode_traits<MODE>::planes == 2) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2)))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
@@ -123,14 +126,16 @@ void attention_kernel(const AttnParams p) {
     // XCD-aware decode of the linear block id L: the q-tiles of one (utterance, head) sit at
     // L, L+8, L+16, ... -> same XCD (blocks are dealt round-robin over the 8 XCDs), close in time,
     // so K/V are fetched from HBM once and re-read from that XCD's L2 by the other q-tiles.
-    const int L = blockIdx.x;
+    int L = blockIdx.x;
+    do {
+    if (PERSIST && L != (int)blockIdx.x) __syncthreads();          // every wave has left the previous item's LDS tiles / bias window
     const int bh = (L / (8 * p.nq)) * 8 + (L & 7), qt = (L >> 3) % p.nq;
-    if (bh >= p.H * p.B) return;
+    if (bh >= p.H * p.B) continue;
     const int h = bh % p.H, b = bh / p.H;
     const int row0 = p.frame_offs[b];
     const int T = p.frame_offs[b + 1] - row0;
     const int q0 = qt * (32 * NWV);
-    if (q0 >= T) return;
+    if (q0 >= T) continue;
     DBG_P(0);
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
@@ -567,11 +572,12 @@ void attention_kernel(const AttnParams p) {
                                      ot[ds][4 * r4 + 2] * inv, ot[ds][4 * r4 + 3] * inv);
             }
     }
+    } while (PERSIST && (L += gridDim.x) < p.nitems);
 }
 
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false, bool PERSIST = false>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D, GB>;
+    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D, GB, PERSIST>;
     static std::atomic<bool> ready{false};          // several host threads launch (see gemm.hip launch_mode)
     if (lds > 65536 && !ready.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -638,8 +644,16 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
 #endif
     p.B = B; p.nq = (max_frames + 32 * nwv - 1) / (32 * nwv);
     dim3 grid((unsigned)(((H * B + 7) / 8) * 8 * p.nq), 1, 1);
+    p.nitems = (int)grid.x;
     hipStream_t s = (hipStream_t)stream;
     const bool pre = scale <= 0.f;
+    {   // SER_ATTN_PERSIST=1 (A/B knob, default 0; the bf16 WavLM form only): 512 resident blocks walk the items
+        static const int persist = [] { const char* e = getenv("SER_ATTN_PERSIST"); return e ? atoi(e) : 0; }();
+        if (persist && pre && table && !gbias && !bias2d && mode == SER_MODE_BF16 && dhp == 64 && nwv == 4 && grid.x > 512u) {
+            grid.x = 512u;
+            return launch_attention<64, SER_MODE_BF16, true, true, 4, false, false, true>(p, grid, lds, s);
+        }
+    }
 #define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
                               : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
     if (gbias) {
