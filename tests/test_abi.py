@@ -28,6 +28,19 @@ def test_binding_covers_header(built_library):
     assert _lib.lib.ser_version() == _lib.ABI_VERSION == int(re.search(r"#define SER_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
 
 
+def test_mode_and_op_constants_match_header(built_library):
+    """SER_MODE_* / SER_ACT_* / SER_OP_* / SER_WS_* of the header are the numbers the ctypes binding passes."""
+    from interspeech_ser_amd import _lib
+    text = open(HEADER).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define (SER_(?:MODE|ACT|OP|WS)_\w+)\s+(\d+)", text)}
+    assert defs["SER_MODE_BF16"] == _lib.MODE_BF16 and defs["SER_MODE_FP32X"] == _lib.MODE_FP32X and defs["SER_MODE_FP16"] == _lib.MODE_FP16
+    assert defs["SER_MODE_FP16X"] == _lib.MODE_FP16X and defs["SER_MODE_FP16Q"] == _lib.MODE_FP16Q
+    assert defs["SER_ACT_NONE"] == _lib.ACT_NONE and defs["SER_ACT_GELU"] == _lib.ACT_GELU
+    assert defs["SER_WS_LOGMEL"] == _lib.WS_LOGMEL and defs["SER_WS_WAVE_FRAMES"] == _lib.WS_WAVE_FRAMES
+    ops = ("GEMM", "ATTENTION", "LAYERNORM", "WAVE_FRAMES", "ROW_CENTER", "LOGMEL", "PACK_ACT")
+    assert [defs["SER_OP_" + o] for o in ops] == [getattr(_lib, "OP_" + o) for o in ops]
+
+
 def test_struct_layouts_match_c(built_library, tmp_path):
     """Every ctypes mirror (ser_gemm_args, the command-list argument structs, ser_cmd) must have the C
     compiler's size and field offsets."""
