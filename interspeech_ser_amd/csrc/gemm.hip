@@ -716,8 +716,10 @@ static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
             else
                 e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>(a, grid, block, LDS, s);
         } else {
-            if (a->mode == SER_MODE_FP16X) return ser_fail(-22, "ser_gemm: the LayerNorm epilogue has no FP16X form");
-            e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>(a, grid, block, LDS, s);
+            if (a->mode == SER_MODE_FP16X)             // conv stack of the f16 / f16q / f16a modes: fp16 hi + lo planes (22-bit operands)
+                e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16X, LNEPI>(a, grid, block, LDS, s);
+            else
+                e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>(a, grid, block, LDS, s);
         }
     } else {
         if (a->mode == SER_MODE_FP16) {
@@ -820,7 +822,6 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         return ser_fail(-21, "ser_gemm: out_mode %d with mode %d (FP32X -> FP16, FP16 <-> FP16X convert)", a->out_mode, a->mode);
     if (a->out_mode && a->out_mode != a->mode && a->ln_gamma)
         return ser_fail(-21, "ser_gemm: out_mode %d with the LayerNorm epilogue", a->out_mode);
-    if (a->mode == SER_MODE_FP16X && a->ln_gamma) return ser_fail(-22, "ser_gemm: the LayerNorm epilogue has no FP16X form");
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
     if ((a->ldo_act % 8) || (a->c_group_stride % 8)) return ser_fail(-18, "ser_gemm: act pitch / group stride must be multiples of 8");
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
@@ -841,7 +842,7 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         // grouped positional conv (<= 64 output channels per group): 128x64 tiles of 32x64 wave tiles, like the bf16 path's -- the
         // 128x128 tile below computes 64 dead columns per group (fp32x pos-conv: 360 us against 100 us in bf16)
         static const int x32_n64 = [] { const char* e = getenv("SER_GEMM_N64"); return e ? atoi(e) : 1; }();
-        if (x32_n64 && a->N <= 64 && a->mode == SER_MODE_FP32X) return launch_cfg<4, 1, 2, 4, 32, 2, false, true>(a, s);
+        if (x32_n64 && a->N <= 64) return launch_cfg<4, 1, 2, 4, 32, 2, false, true>(a, s);
         // Large grids: 256x128 tiles of 64x64 wave tiles on a 32-deep, 3-stage ring (144 KiB): 16 fragments feed 48 MFMAs per
         // k-step (0.33 LDS fragment reads per MFMA against 0.5 for the 32x64 wave tile below), one ping-pong phase per K tile
         static const long x32_256_min = [] { const char* e = getenv("SER_GEMM_X32_256_MIN"); return e ? atol(e) : 100L; }();   // 100: M = 3992 out-proj / FC2 (128 tiles) gain, M = 1996 ones (64 tiles) lose

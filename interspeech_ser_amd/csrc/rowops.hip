@@ -112,7 +112,7 @@ extern "C" int ser_wave_frames(const float* wav, const int64_t* sample_offs, con
                                void* stream) {
     if (!wav || !sample_offs || !frame_offs || !out || !work) return ser_fail(-1, "ser_wave_frames: null pointer");
     if (B <= 0 || k < 1 || k > 64 || stride < 1 || total_rows <= 0) return ser_fail(-2, "ser_wave_frames: bad B/k/stride/rows");
-    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_wave_frames: bad mode");
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X && mode != SER_MODE_FP16X) return ser_fail(-3, "ser_wave_frames: bad mode");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(wave_stats_kernel, dim3(64, B), dim3(256), 0, s, wav, sample_offs, (double*)work);
     int blocks = ((total_rows + B - 1) / B + 31) / 32;
@@ -120,6 +120,9 @@ extern "C" int ser_wave_frames(const float* wav, const int64_t* sample_offs, con
     if (blocks < 1) blocks = 1;
     if (mode == SER_MODE_FP32X)
         hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_FP32X>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
+                           (const double*)work, (unsigned short*)out, out_plane_stride, k, stride);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_FP16X>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
                            (const double*)work, (unsigned short*)out, out_plane_stride, k, stride);
     else
         hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_BF16>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
@@ -653,6 +656,9 @@ extern "C" int ser_pack_act(const float* x, int B, int C, int T, int halo, void*
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (mode == SER_MODE_FP32X)
         hipLaunchKernelGGL(pack_act_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
+                           (unsigned short*)out, ldo, out_plane_stride);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(pack_act_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
                            (unsigned short*)out, ldo, out_plane_stride);
     else
         hipLaunchKernelGGL(pack_act_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,

@@ -52,6 +52,8 @@ _NO_SHIFT = _os.environ.get("SER_NO_SHIFT", "0") == "1"
 # 12 column tiles of 256 wide instead of 13 (N = 3D + 32).  Measured (round 3, two A/B pairs): bf16 1 941 / 1 940 -> 1 933 / 1 937 utt/s,
 # f16a 1 103 -> 1 098: the extra launch (its own deferred-LayerNorm prologue, 63 blocks) costs what the 13th tile column does.  Default 0.
 _SPLIT_GATE = _os.environ.get("SER_SPLIT_GATE", "0") == "1"
+# A/B knob: SER_STEM_F16X=0 puts the stem of the f16 / f16q / f16a modes back on bf16 hi + lo planes (rounds 2 / early 3)
+_STEM_F16X = _os.environ.get("SER_STEM_F16X", "1") == "1"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -200,7 +202,10 @@ class _EncoderBase:
         self.device = torch.device(device)
         self.mode_name = mode
         self.mode = MODES[mode]                                   # encoder layers
-        self.stem_mode = _lib.MODE_FP32X if mode in ("f16", "f16q", "f16a") else self.mode      # conv stem (+ projection, positional conv)
+        # conv stem (+ projection, positional conv): the 3-product split in every parity mode.  The fp16-layer modes take it on fp16 hi + lo
+        # planes (22-bit operands, round 3) rather than bf16 hi + lo (16-bit, the "fp32x" mode's): same cost, and the stem's share of the error
+        # -- which sharp attention amplifies like any other -- drops by the 6 extra bits per operand
+        self.stem_mode = (_lib.MODE_FP16X if _STEM_F16X else _lib.MODE_FP32X) if mode in ("f16", "f16q", "f16a") else self.mode
         self.qk_mode = _lib.MODE_FP16X if mode == "f16q" else None             # logit path on its own launch (None: one packed launch)
         self.attn_mode = _lib.MODE_FP16X if mode == "f16a" else self.mode      # packed projection, context rows, output projection
         self.x_mode = self.qk_mode or self.attn_mode                           # format of the operand copy the packed projection reads
