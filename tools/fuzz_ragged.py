@@ -1,7 +1,7 @@
 """Randomised ragged-batch shake-out (GPU box, a few minutes): tiny geometries of the three speech families, random batch sizes
 and utterance lengths through ONE long-lived encoder per (family, mode) -- arenas grow and shrink, command lists are patched --
 checking (1) batched == batch-of-one bit for bit on a sampled utterance, (2) the command-list path == the launch-by-launch path,
-(3) fp32x / f16 / bf16 within their tolerances of the CPU oracle on a sampled utterance."""
+(3) fp32x / f16a / f16q / f16 / bf16 within their tolerances of the CPU oracle on a sampled utterance."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,8 @@ from interspeech_ser_amd.weights import synthetic_state_dict
 from oracle import ssl_oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-TOL = {"fp32x": 1e-3, "f16": 1e-3, "bf16": 3e-2}
+TOL = {"fp32x": 1e-3, "f16a": 1e-3, "f16q": 1e-3, "f16": 1e-3, "bf16": 3e-2}
+MODES = tuple(TOL)
 fams = [("wavlm", C.TINY_WAVLM), ("hubert", C.TINY_HUBERT), ("wav2vec2", C.TINY_WAV2VEC2)]
 encs = {}
 t_end = time.time() + budget
@@ -19,7 +20,7 @@ n = 0
 worst = {m: 0.0 for m in TOL}
 while time.time() < t_end:
     fam, geo = fams[int(rng.integers(len(fams)))]
-    mode = ("fp32x", "f16", "bf16")[int(rng.integers(3))]
+    mode = MODES[int(rng.integers(len(MODES)))]
     key = (fam, mode)
     if key not in encs:
         sd = synthetic_state_dict(geo, 100 + len(encs))
@@ -36,6 +37,14 @@ while time.time() < t_end:
     b = eager.forward(eager.upload(waves), lens)
     torch.cuda.synchronize()
     assert a.frame_offs == b.frame_offs and torch.equal(a.states, b.states), ("tape != eager", key, lens)
+    if rng.integers(4) == 0:                                  # early exit: the states it leaves equal the full forward's, bit for bit
+        nstop = int(rng.integers(geo.num_layers + 1))
+        full = a.states.clone()
+        part = taped.forward(taped.upload(waves), lens, last_state=nstop)
+        torch.cuda.synchronize()
+        assert torch.equal(part.states[: nstop + 1], full[: nstop + 1]), ("early exit", key, lens, nstop)
+        a = taped.forward(taped.upload(waves), lens)
+        torch.cuda.synchronize()
     assert bool(torch.isfinite(a.states).all()), ("non-finite", key, lens)
     j = int(rng.integers(B))
     keep = [a.utterance(j, l).clone() for l in range(len(a))]
