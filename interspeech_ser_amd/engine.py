@@ -1390,6 +1390,8 @@ class DebertaEncoder(_EncoderBase):
 def mean_last4(hs: HiddenStates) -> torch.Tensor:
     """``--use_average y``: mean of the last four states (preprocess_speech.py:52-63), on the GPU."""
     s = hs.states
+    if getattr(hs, "computed", s.shape[0]) < s.shape[0]:
+        raise IndexError("mean of the last four states needs the full forward (this one stopped early: last_state)")
     out = torch.empty_like(s[0])
     n = out.numel()
     check(lib.ser_mean4(s[-4].data_ptr(), s[-3].data_ptr(), s[-2].data_ptr(), s[-1].data_ptr(), out.data_ptr(), n, _stream()),
