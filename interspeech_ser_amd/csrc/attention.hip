@@ -84,6 +84,9 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 // and the bias path does not zero accumulators it is about to overwrite.
 // NWV waves (x 32 queries) per block.  8 waves halve the K/V global->LDS traffic and the bias-row copies per query:
 // used for bf16 head dims <= 64 once an utterance has more than one 128-query tile.
+#ifndef SER_ATTN_LAZY
+#define SER_ATTN_LAZY 1          // pre-scaled launches keep a STALE row maximum inside the accumulators' start value (see the tile loop)
+#endif
 #ifndef SER_ATTN_MINW
 #define SER_ATTN_MINW 2          // waves per SIMD the register allocation must leave room for (A/B knob at build time)
 #endif
@@ -315,7 +318,15 @@ void attention_kernel(const AttnParams p) {
     for (int i = 0; i < DSUB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    // LAZY (pre-scaled q + WavLM bias table): the S accumulators start at gate * bias - m_run instead of gate * bias -- the same one FMA per
+    // score -- so the MFMA chain delivers scores already relative to the running maximum and the exponentials need no subtraction; m_run is
+    // only raised when a tile's scores exceed it by more than LAZY_T (P <= 2^LAZY_T: far inside fp32 / fp16 range), which after the first
+    // tiles is rare, and O and l are rescaled in that branch only.  O / l is unchanged: every P of a row carries the same factor
+    // 2^(m_true - m_run).  Measured (tools/attn_lazy_ab.sh, two A/B pairs): WavLM-large step 1 968 / 1 974 -> 1 988 / 1 985 utt/s.  Without a
+    // bias table the start value needs its own 16-register block that hipcc copies per tile: Whisper 380.4 -> 377.2, so those keep the exact maximum.
+    constexpr bool LAZY = SER_ATTN_LAZY && PRE && TBL;
+    constexpr float LAZY_T = 8.0f;
+    float m_run = LAZY ? 0.f : -1e30f, l_run = 0.f;
 #ifdef SER_ATTN_DBG
     const bool dbg_on = p.dbg && (int)blockIdx.x == ser_attn_dbg_block_dev;
     if (dbg_on && lane == 0) p.dbg[(wave * 64 + 63) * 6] = __builtin_amdgcn_s_memtime();     // end of the prologue loads' issue
@@ -378,7 +389,9 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = (PRE && TBL) ? gq2 * bvv[sub][g4][r] : ((PRE && B2D) ? bvv[sub][g4][r] : 0.f);
+                    for (int r = 0; r < 4; ++r)
+                        st[sub][4 * g4 + r] = (PRE && TBL) ? (LAZY ? fmaf(gq2, bvv[sub][g4][r], -m_run) : gq2 * bvv[sub][g4][r])
+                                                           : ((PRE && B2D) ? bvv[sub][g4][r] : 0.f);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)                          // the two key halves are independent chains
 #pragma unroll
@@ -393,7 +406,7 @@ void attention_kernel(const AttnParams p) {
                         const int kb = kt * ABKV + sub * 32 + 8 * g4 + 4 * hh;
                         const f32x4 bv = bias_quad(kb, RAGGED);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = gq2 * bv[r];
+                        for (int r = 0; r < 4; ++r) st[sub][4 * g4 + r] = LAZY ? fmaf(gq2, bv[r], -m_run) : gq2 * bv[r];
                     }
                 } else if (PRE && B2D) {
 #pragma unroll
@@ -468,43 +481,77 @@ void attention_kernel(const AttnParams p) {
             mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
         DBG_T(2);
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        if (!__all(alpha == 1.0f)) {                                 // wave-uniform: most tiles after the first few skip it
+        float m_new = 0.f, alpha = 1.0f;                             // LAZY: the scores are already relative to m_run
+        if constexpr (LAZY) {
+            if (kt == 0 || !__all(mloc <= LAZY_T)) {                 // wave-uniform; kt == 0: nothing accumulated yet, take the tile's own maximum
+                const float d = kt == 0 ? (mloc > -1e29f ? mloc : 0.f) : fmaxf(mloc, 0.f);   // (a query whose first tile is all padding: 0)
+                m_run += d;
+                if (kt != 0) {
+                    alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-            for (int i = 0; i < DSUB; ++i)
+                    for (int i = 0; i < DSUB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+                }
+                const f32x2 d2 = {d, d};
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 v = (f32x2){st[sub][r], st[sub][r + 1]} - d2;
+                        st[sub][r] = v[0]; st[sub][r + 1] = v[1];
+                    }
+            }
+        } else {
+            m_new = fmaxf(m_run, mloc);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            if (!__all(alpha == 1.0f)) {                             // wave-uniform: most tiles after the first few skip it
+#pragma unroll
+                for (int i = 0; i < DSUB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+            }
         }
 
         // ---- P = exp2(S - m) and O^T += V^T P^T, 16 keys at a time: accumulator registers 8s..8s+7 of a key half
         // are the B fragment of k-step s, so the exponentials of the next 16 keys issue while these MFMAs run
-        float lsum = 0.f;
+        f32x2 lsum2 = {0.f, 0.f};                                    // LAZY: the row sum through v_pk_add_f32 (two scores per VALU issue)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 ph, plo;
-                if constexpr (mode_traits<MODE>::f16) {
-                    f16x8 p16, p16lo;                                // P in [0, 1]: no saturation needed
+                float e[8];
+                if constexpr (LAZY) {
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2 ee = {__builtin_amdgcn_exp2f(st[sub][8 * s2 + j]), __builtin_amdgcn_exp2f(st[sub][8 * s2 + j + 1])};
+                        lsum2 += ee;
+                        e[j] = ee[0]; e[j + 1] = ee[1];
+                    }
+                } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float e = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
-                        lsum += e;
-                        p16[j] = (_Float16)e;
-                        if (NPV == 2) p16lo[j] = (_Float16)(e - (float)p16[j]);
+                        e[j] = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
+                        lsum2[0] += e[j];
+                    }
+                }
+                if constexpr (mode_traits<MODE>::f16) {
+                    f16x8 p16, p16lo;                                // P in [0, 1] (LAZY: [0, 2^LAZY_T]): no saturation needed
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        p16[j] = (_Float16)e[j];
+                        if (NPV == 2) p16lo[j] = (_Float16)(e[j] - (float)p16[j]);
                     }
                     ph = __builtin_bit_cast(bf16x8, p16);
                     if (NPV == 2) plo = __builtin_bit_cast(bf16x8, p16lo);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float e = __builtin_amdgcn_exp2f(st[sub][8 * s2 + j] - m_new);
-                        lsum += e;
-                        const __bf16 hi = (__bf16)e;
+                        const __bf16 hi = (__bf16)e[j];
                         ph[j] = hi;
-                        if (NPV == 2) plo[j] = (__bf16)(e - (float)hi);
+                        if (NPV == 2) plo[j] = (__bf16)(e[j] - (float)hi);
                     }
                 }
 #pragma unroll
@@ -520,8 +567,10 @@ void attention_kernel(const AttnParams p) {
                     }
                 }
             }
+        float lsum;
         {   // the other half-wave summed the other 32 keys of this query
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+            const float lh = lsum2[0] + lsum2[1];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lh), __float_as_uint(lh), false, false);
             lsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         }
         l_run = l_run * alpha + lsum;

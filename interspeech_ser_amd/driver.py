@@ -166,9 +166,16 @@ class _Extractor:
             out.append(rows)
         return out
 
-    # ---- pipelined form: two slots (arena + HIP stream each), so batch i+1 is uploaded and launched while batch i
-    # still computes, and its D2H copy / slicing / torch.save overlap the next forward
-    SLOTS = 2
+    # ---- pipelined form: SLOTS slots (arena + HIP stream each), so batch i+1 is uploaded and launched while batch i
+    # still computes, and its D2H copy / slicing / torch.save overlap the next forward.  The kernels of at most RUNNING
+    # batches share the GPU (the regime bench.py times: two whole batches in flight).  SER_PIPE_SLOTS=3 keeps a third batch
+    # uploaded and enqueued behind an event, so the GPU never drops to ONE batch while the launching thread collects a
+    # finished one; measured (tools/pipe_slots_ab.sh, two A/B pairs on one box): 1 866 / 1 866 -> 1 881 / 1 888 utt/s end to
+    # end at full depth, but 5 617 / 5 239 -> 4 812 / 4 993 for the reference's default rule (stem only, host-bound) -- so
+    # two slots stay the default.  What separates the end-to-end rate from the kernels' 2 015 is stream launches instead of
+    # a replayed hipGraph (ragged batches change every launch's sizes), not an idle GPU: the launching thread waits.
+    SLOTS = max(2, int(os.environ.get("SER_PIPE_SLOTS", "2")))
+    RUNNING = 2
 
     def submit(self, waves: List[np.ndarray], layer_index: int, slot: int):
         """Enqueue upload -> forward -> selection -> D2H of one ragged batch on slot ``slot``'s stream; returns a
@@ -180,13 +187,20 @@ class _Extractor:
         lengths = [len(w) for w in waves]
         tm = self.__dict__.setdefault("tm", dict(upload=0.0, forward=0.0, d2h=0.0))
         clock = time.perf_counter
+        computed = self.__dict__.setdefault("_computed", [])      # "kernels done" events of the batches submitted so far, oldest first
         with torch.cuda.stream(st[slot]):
             t0 = clock()
             dev = self.enc.upload(waves, slot)
             t1 = clock()
+            if len(computed) >= self.RUNNING:                     # start once the batch RUNNING places ahead has left the compute units
+                st[slot].wait_event(computed[-self.RUNNING])
             hs = self.enc.forward(dev, lengths, slot=slot, last_state=None if self.average else layer_index)
             t2 = clock()
             sel = mean_last4(hs) if self.average else hs.states[layer_index]
+            ce = torch.cuda.Event()
+            ce.record()
+            computed.append(ce)
+            del computed[: -self.SLOTS]
             host = self._pinned_out(slot, sel.shape[0], sel.shape[1])
             host.copy_(sel, non_blocking=True)
             evt = torch.cuda.Event()
@@ -414,7 +428,7 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, l
                         finish(inflight.popleft())
                     one_by_one(good)
             t_a = clock()
-            while len(inflight) > 1:                          # one batch stays in flight while the next is prepared
+            while len(inflight) > getattr(ex, "SLOTS", 2) - 1:   # all but one slot stay in flight while the next batch is prepared
                 finish(inflight.popleft())
             tm["finish"] += clock() - t_a
             bar.update(len(batch))

@@ -980,7 +980,7 @@ class WhisperEncoder(_EncoderBase):
             pl = self._build_plan(len(lengths), slot)
         else:
             self._cache[(slot, len(lengths))] = pl      # re-insert: the dict is kept in least-recently-USED order, the hot
-            #                                             full-batch plans of the two pipeline slots are never the ones evicted
+            #                                             full-batch plans of the pipeline slots are never the ones evicted
         if pl["lengths"] != lengths:
             if pl["offs_evt"] is not None:
                 pl["offs_evt"].synchronize()
@@ -1021,7 +1021,7 @@ class WhisperEncoder(_EncoderBase):
         pl["states"] = torch.empty((geo.num_layers + 1, M, D), dtype=torch.float32, device=dev)
         pl["first_groups"] = 2
         self._layer_buffers(pl, M, pl["first_groups"])
-        if len(self._cache) >= 6:                       # two pipeline slots x (full batch, tail batch) + slack
+        if len(self._cache) >= 9:                       # three pipeline slots x (full batch, tail batch, retry of one) before anything is evicted
             self._cache.pop(next(iter(self._cache)))
         self._cache[key_full] = pl
         return pl

@@ -136,15 +136,21 @@ def test_row_center_fp16x(L):
     assert torch.equal(xa[0].cpu(), cen.float().to(torch.float16))
 
 
-def _attention_case(L, dh, H, bias, sharp, mode):
+def _attention_case(L, dh, H, bias, sharp, mode, Ts=(70, 129, 5, 200), ramp=0.0):
     """[q | k | gate | v] layout of the "f16q" mode; q pre-scaled by dh^-0.5 * log2(e).  Returns (max abs error vs fp64, reference)."""
-    Ts = [70, 129, 5, 200]
+    Ts = list(Ts)
     D, M, Tmax = H * dh, sum(Ts), max(Ts)
     gpad = 8 if bias else 0
     ld = 3 * D + gpad
     g = torch.Generator().manual_seed(dh + H + int(sharp))
     qkv = torch.randn(M, ld, generator=g)
     qkv[:, : 2 * D] *= sharp ** 0.5                       # logits grow with `sharp`: near one-hot softmax rows at 8-16
+    if ramp:                                              # scores that climb with the key position (see test_attention_stale_running_maximum)
+        u = torch.ones(dh) / dh ** 0.5
+        pos = torch.cat([torch.arange(T) / max(T - 1, 1) for T in Ts])
+        for h in range(H):
+            qkv[:, h * dh:(h + 1) * dh] += 3.0 * u
+            qkv[:, D + h * dh: D + (h + 1) * dh] += (ramp * pos)[:, None] * u
     c = dh ** -0.5 * 1.4426950408889634
     pre = qkv.clone()
     pre[:, :D] *= c
@@ -193,6 +199,15 @@ def test_attention_fp16x(L, dh, H, bias):
     """everything split ("f16a"): S, P V on 3 products, the context rows written as fp16 hi + lo planes -- fp32-grade"""
     err, ref = _attention_case(L, dh, H, bias, 1.0, FP16X)
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("mode,bound", [(FP16Q, 3e-3), (FP16X, 2e-5)])
+@pytest.mark.parametrize("dh,bias", [(64, True), (128, False)])
+def test_attention_two_plane_stale_running_maximum(L, mode, bound, dh, bias):
+    """the stale-maximum branch of the bias-table launches (csrc/attention.hip, LAZY) and the exact-maximum rescale of the others on the
+    two-plane forms: 11 key tiles of climbing scores"""
+    err, ref = _attention_case(L, dh, 2, bias, 1.0, mode, Ts=(700, 65, 1, 130), ramp=100.0)
+    assert err < bound, err
 
 
 def test_gemm_fp16x_writes_one_plane(L):

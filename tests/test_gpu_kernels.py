@@ -709,16 +709,23 @@ def test_attention_fused_gate_columns(L, mode):
     assert err < mode_tol(mode, 3e-2, 1e-4), err
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("dh,bias", [(64, True), (64, False), (120, False)])
-def test_attention_prescaled_q(L, mode, dh, bias):
-    """scale <= 0: q arrives multiplied by dh^-0.5*log2(e) (projection epilogue); scores are exp2 exponents and,
-    with a bias table, the MFMA accumulators start at gate*bias."""
-    Ts, H = [150, 64, 333], 2
+def _prescaled_case(L, mode, dh, bias, Ts, ramp=0.0):
+    H = 2
     D, M = H * dh, sum(Ts)
     g = torch.Generator().manual_seed(dh)
     qkv = torch.randn(M, 3 * D, generator=g)
     qkv[:, : 2 * D] *= 1.5
+    if ramp:                                                   # scores that climb with the key position, and one late spike per utterance
+        u = torch.ones(dh) / dh ** 0.5
+        pos = torch.cat([torch.arange(T) / max(T - 1, 1) for T in Ts])
+        for h in range(H):
+            qkv[:, h * dh:(h + 1) * dh] += 3.0 * u
+            qkv[:, D + h * dh: D + (h + 1) * dh] += (ramp * pos)[:, None] * u
+        o0 = 0
+        for T in Ts:
+            if T > 40:
+                qkv[o0 + T - 20, D: D + dh] += qkv[o0 + 7, :dh] * 6.0    # head 0: key T-20 lines up with query 7
+            o0 += T
     pre = qkv.clone()
     pre[:, :D] *= dh ** -0.5 * 1.4426950408889634
     qa = to_act(pre, mode)
@@ -745,8 +752,28 @@ def test_attention_prescaled_q(L, mode, dh, bias):
                                 td.data_ptr() if bias else None, Tmax if bias else 0, gd.data_ptr() if bias else None,
                                 out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, None, None, 0, stream()))
     torch.cuda.synchronize()
-    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert bool(torch.isfinite(out.float()).all())
+    return (act_value(out).cpu().double() - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dh,bias", [(64, True), (64, False), (120, False)])
+def test_attention_prescaled_q(L, mode, dh, bias):
+    """scale <= 0: q arrives multiplied by dh^-0.5*log2(e) (projection epilogue); scores are exp2 exponents and,
+    with a bias table, the MFMA accumulators start at gate*bias."""
+    err = _prescaled_case(L, mode, dh, bias, [150, 64, 333])
     assert err < mode_tol(mode, 3e-2, 1e-4), err
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("dh,bias", [(64, True), (64, False), (80, False), (128, False)])
+def test_attention_stale_running_maximum(L, mode, dh, bias):
+    """Pre-scaled launches with a bias table keep a STALE row maximum in the accumulators' start value and only raise it when a tile
+    exceeds it by 2^8 (csrc/attention.hip, LAZY); the others track the exact maximum.  Scores that climb ~50 exp2-units across 11 key
+    tiles plus a late spike drive the raise / rescale branch every other tile; utterances of 1 and 65 frames cover a first tile that is
+    (almost) all padding.  (fp32x bound: one-hot rows over |v| ~ 4 with logits of +-100 -- 1.5e-4 on either form.)"""
+    err = _prescaled_case(L, mode, dh, bias, [700, 65, 1, 130], ramp=100.0)
+    assert err < mode_tol(mode, 3e-2, 3e-4), err
 
 
 def test_gemm_column_scale(L):
