@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 11
+#define SER_ABI_VERSION 12
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -159,6 +159,8 @@ typedef struct ser_gemm_args {
                                     * mode == SER_MODE_FP16X writes one plane from a 3-product GEMM (output projection -> FC1, "f16a") */
     const float*   ln_shift;       /* [M] shift of the A rows / their partials (consumer), or NULL */
     float*         mean_out;       /* [M] absolute row mean of the A rows (consumer), or NULL */
+    float*         lnstat_out;     /* [M][2] (row mean relative to ln_shift, 1/sqrt(var + eps)) the consumer derived from ln_stats_in, or
+                                    * NULL: what ser_attention's in-kernel WavLM gate (ser_attention_args.gate_x) applies to the same rows */
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
 
@@ -298,7 +300,20 @@ typedef struct ser_attention_args {
     int32_t H, dh; float scale; int32_t mode; int32_t gate_col, reserved0;
     const float* gru_const; const int32_t* key_lens;
     const float* bias2d; int64_t bias2d_ld;
+    /* WavLM gate computed INSIDE the kernel (round 3; ser_attention_v only): the two pre-activations per (row, head) are linear in
+     * LayerNorm1(x) restricted to the head's dh channels (HF modeling_wavlm.py:167-180), so instead of riding along as 2H extra output
+     * columns of the packed projection (gate_col: a 13th 256-wide column tile for 32 columns at D = 1024) every query reads its own dh
+     * elements of the layer input's operand copy and applies the deferred LayerNorm in closed form:
+     *   pre_j = rstd * (sum_d x[d] * gate_w[h*dh + d][j] - mean * gate_cb[h][j]) + gate_cb[h][2 + j],   j = 0, 1
+     * gate_x = that copy (the A operand of the packed projection, element type of `mode`, gate_x_planes planes), gate_stat = the
+     * projection's ser_gemm_args.lnstat_out, gate_w = gamma-folded summed weights, gate_cb = (column sums | beta W^T + b).  Needs table
+     * and gru_const; gate and gate_col are ignored. */
+    const void* gate_x; int64_t gate_x_ld; int64_t gate_x_plane_stride;
+    const float* gate_stat; const float* gate_w; const float* gate_cb;
+    int32_t gate_x_planes, reserved1;
 } ser_attention_args;
+/* ser_attention with its arguments in a struct (the form command lists carry); the only entry point that takes the gate_x fields. */
+int ser_attention_v(const ser_attention_args* args, void* stream);
 
 typedef struct ser_layernorm_args {
     const float* x; int64_t ldx; const float* g; const float* b; float eps; int32_t gelu;

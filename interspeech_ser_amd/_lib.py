@@ -24,7 +24,7 @@ ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
 WS_WAVE_FRAMES = 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -47,7 +47,7 @@ class GemmArgs(C.Structure):
         ("stat_out", c_void_p), ("stat_groups", C.c_int32), ("f32_col_begin", C.c_int32),
         ("col_scale", c_float), ("col_scale_end", C.c_int32),
         ("shift_in", c_void_p), ("shift_out", c_void_p), ("shift_const", c_float), ("out_mode", C.c_int32),
-        ("ln_shift", c_void_p), ("mean_out", c_void_p),
+        ("ln_shift", c_void_p), ("mean_out", c_void_p), ("lnstat_out", c_void_p),
     ]
 
 
@@ -63,6 +63,9 @@ class AttentionArgs(C.Structure):
         ("gate_col", C.c_int32), ("reserved0", C.c_int32),
         ("gru_const", c_void_p), ("key_lens", c_void_p),
         ("bias2d", c_void_p), ("bias2d_ld", c_i64),
+        ("gate_x", c_void_p), ("gate_x_ld", c_i64), ("gate_x_plane_stride", c_i64),
+        ("gate_stat", c_void_p), ("gate_w", c_void_p), ("gate_cb", c_void_p),
+        ("gate_x_planes", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -138,6 +141,7 @@ _SIGNATURES = {
                                c_int, c_void_p]),
     "ser_attention": (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                               c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "ser_attention_v": (c_int, [c_void_p, c_void_p]),
     "ser_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                              c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ser_logmel_init": (c_int, [c_void_p, c_int, c_void_p]),

@@ -43,6 +43,13 @@ struct AttnParams {
     const float* gate;
     const float* gru_const;
     int gate_col;
+    // gate pre-activations computed here from the layer input's operand copy (ser_attention_args.gate_x)
+    const unsigned short* gx;
+    int64_t gx_ld, gx_plane;
+    int gx_planes;
+    const float* gstat;        // [rows][2] relative mean, rstd (ser_gemm lnstat_out)
+    const float* gw;           // [H*dh][2]
+    const float* gcb;          // [H][4]
     unsigned short* out;
     int64_t ldo, out_plane;
     int H, dh, B, nq;
@@ -258,9 +265,29 @@ void attention_kernel(const AttnParams p) {
             }
     }
     float g_in0 = 0.f, g_in1 = 0.f, g_c = 0.f;                     // raw gate inputs (consumed after the bias copy)
+    // in-kernel gate: this half-wave's 8-element chunks (c = 2 i + hh) of the query row's head slice of the layer input, both planes,
+    // and the matching rows of the folded weights; requested here, multiplied after the bias copy
+    constexpr int GCH = TBL ? DHP / 16 : 1;
+    u32x4 gxv[2][GCH];
+    f32x4 gwv[GCH][4];
+    f32x2 gst = {0.f, 1.f};
     if (TBL) {
         if (p.gate) {
             g_in0 = p.gate[(int64_t)(row0 + qc) * p.H + h];
+        } else if (p.gx) {
+            const unsigned short* xr = p.gx + (int64_t)(row0 + qc) * p.gx_ld + h * dh;
+            const float* wr = p.gw + (int64_t)h * dh * 2;
+#pragma unroll
+            for (int i = 0; i < GCH; ++i) {
+                const int d = (2 * i + hh) * 8;
+                const bool on = d < dh;
+                gxv[0][i] = on ? *(const u32x4*)(xr + d) : (u32x4){0u, 0u, 0u, 0u};
+                gxv[1][i] = (on && p.gx_planes == 2) ? *(const u32x4*)(xr + p.gx_plane + d) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gwv[i][j] = on ? *(const f32x4*)(wr + 2 * d + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            gst = *(const f32x2*)(p.gstat + 2 * (int64_t)(row0 + qc));
+            g_c = p.gru_const[h];
         } else {
             // gate pre-activations ride along as two extra columns per head of the packed projection
             const unsigned short* gp = p.qkv + (int64_t)(row0 + qc) * p.ld + p.gate_col + 2 * h;
@@ -286,6 +313,29 @@ void attention_kernel(const AttnParams p) {
     const float c1 = p.scale * LOG2E;
     float gq2 = 0.f;
     if (TBL) {
+        if (!p.gate && p.gx) {
+            float da = 0.f, db = 0.f;
+#pragma unroll
+            for (int i = 0; i < GCH; ++i) {
+                typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+                const u16x8 eh = __builtin_bit_cast(u16x8, gxv[0][i]), el = __builtin_bit_cast(u16x8, gxv[1][i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = elem2f<MODE>(eh[e]) + elem2f<MODE>(el[e]);      // lo plane: zeros when there is none
+                    da = fmaf(x, gwv[i][e >> 1][2 * (e & 1)], da);
+                    db = fmaf(x, gwv[i][e >> 1][2 * (e & 1) + 1], db);
+                }
+            }
+            {   // the other half-wave multiplied the other chunks of the same query row
+                const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(da), __float_as_uint(da), false, false);
+                const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(db), __float_as_uint(db), false, false);
+                da = __uint_as_float(sa[0]) + __uint_as_float(sa[1]);
+                db = __uint_as_float(sb[0]) + __uint_as_float(sb[1]);
+            }
+            const f32x4 cb = *(const f32x4*)(p.gcb + 4 * h);
+            g_in0 = fmaf(gst[1], da - gst[0] * cb[0], cb[2]);           // deferred LayerNorm 1 in closed form (ser_hip.h)
+            g_in1 = fmaf(gst[1], db - gst[0] * cb[1], cb[3]);
+        }
         if (p.gate) {
             gq2 = g_in0 * LOG2E;
         } else {
@@ -642,7 +692,30 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
                              const float* gate, void* out, int64_t ldo, int64_t out_plane_stride, int H, int dh,
                              float scale, int mode, int gate_col, const float* gru_const, const int32_t* key_lens,
                              const float* bias2d, int64_t bias2d_ld, void* stream) {
+    ser_attention_args a = {};
+    a.qkv = qkv; a.ld = ld; a.plane_stride = plane_stride; a.q_col = q_col; a.k_col = k_col; a.v_col = v_col; a.B = B;
+    a.frame_offs = frame_offs; a.table = table; a.gate = gate; a.max_frames = max_frames; a.table_T = table_T;
+    a.out = out; a.ldo = ldo; a.out_plane_stride = out_plane_stride; a.H = H; a.dh = dh; a.scale = scale; a.mode = mode;
+    a.gate_col = gate_col; a.gru_const = gru_const; a.key_lens = key_lens; a.bias2d = bias2d; a.bias2d_ld = bias2d_ld;
+    return ser_attention_v(&a, stream);
+}
+
+extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
+    if (!args) return ser_fail(-1, "ser_attention: null pointer");
+    const void* qkv = args->qkv; const int64_t ld = args->ld, plane_stride = args->plane_stride;
+    const int q_col = args->q_col, k_col = args->k_col, v_col = args->v_col, B = args->B, max_frames = args->max_frames;
+    const int32_t* frame_offs = args->frame_offs; const float* table = args->table; const int table_T = args->table_T;
+    const float* gate = args->gate; void* out = args->out; const int64_t ldo = args->ldo, out_plane_stride = args->out_plane_stride;
+    const int H = args->H, dh = args->dh, mode = args->mode, gate_col = args->gate_col; const float scale = args->scale;
+    const float* gru_const = args->gru_const; const int32_t* key_lens = args->key_lens;
+    const float* bias2d = args->bias2d; const int64_t bias2d_ld = args->bias2d_ld;
     if (!qkv || !frame_offs || !out) return ser_fail(-1, "ser_attention: null pointer");
+    if (args->gate_x) {
+        if (!table || !gru_const || gate || !args->gate_stat || !args->gate_w || !args->gate_cb)
+            return ser_fail(-13, "ser_attention: gate_x needs table, gru_const, gate_stat, gate_w, gate_cb and no gate[]");
+        if ((args->gate_x_ld % 8) || (args->gate_x_plane_stride % 8) || args->gate_x_planes < 1 || args->gate_x_planes > 2)
+            return ser_fail(-13, "ser_attention: gate_x pitch / planes");
+    }
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
     if ((ld % 8) || (ldo % 4) || (q_col % 8) || (k_col % 8) || (v_col % 8)) return ser_fail(-4, "ser_attention: misaligned pitches/columns");
@@ -650,7 +723,7 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     if ((table != nullptr) != (gate != nullptr || gru_const != nullptr))
         return ser_fail(-6, "ser_attention: the bias table needs a gate (gate[] or gate_col + gru_const) and vice versa");
     if (gate && gru_const) return ser_fail(-9, "ser_attention: give gate[] or gru_const, not both");
-    if (gru_const && (gate_col < 0 || (gate_col % 2))) return ser_fail(-10, "ser_attention: bad gate_col %d", gate_col);
+    if (gru_const && !args->gate_x && (gate_col < 0 || (gate_col % 2))) return ser_fail(-10, "ser_attention: bad gate_col %d", gate_col);
     if (table && table_T < max_frames) return ser_fail(-7, "ser_attention: bias table built for T=%d < max_frames=%d", table_T, max_frames);
     if (bias2d) {
         if (table || !key_lens || scale > 0.f || dh > 64 || mode == SER_MODE_FP16 || mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q)
@@ -685,6 +758,8 @@ extern "C" int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, 
     p.q_col = q_col; p.k_col = k_col; p.v_col = v_col;
     p.frame_offs = frame_offs; p.key_lens = key_lens; p.table = table; p.table_T = table_T; p.gate = gate;
     p.gru_const = gru_const; p.gate_col = gate_col;
+    p.gx = (const unsigned short*)args->gate_x; p.gx_ld = args->gate_x_ld; p.gx_plane = args->gate_x_plane_stride;
+    p.gx_planes = args->gate_x_planes; p.gstat = args->gate_stat; p.gw = args->gate_w; p.gcb = args->gate_cb;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
     p.bias2d = bias2d; p.b2d_ld = bias2d_ld; p.b2d_T = max_frames;

@@ -50,10 +50,7 @@ extern "C" int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void*
                 rc = ser_gemm(&c.u.gemm, stream);
                 break;
             case SER_OP_ATTENTION: {
-                const ser_attention_args& a = c.u.attention;
-                rc = ser_attention(a.qkv, a.ld, a.plane_stride, a.q_col, a.k_col, a.v_col, a.frame_offs, a.B, a.max_frames,
-                                   a.table, a.table_T, a.gate, a.out, a.ldo, a.out_plane_stride, a.H, a.dh, a.scale, a.mode,
-                                   a.gate_col, a.gru_const, a.key_lens, a.bias2d, a.bias2d_ld, stream);
+                rc = ser_attention_v(&c.u.attention, stream);
                 break;
             }
             case SER_OP_LAYERNORM: {

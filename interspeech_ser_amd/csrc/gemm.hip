@@ -237,6 +237,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             lnst[2 * r + 1] = rsqrtf(var + p.ln_eps);
             // absolute row mean of the A rows (their partials are relative to ln_shift): the next producer's shift
             if (p.mean_out && nt == 0 && g == 0 && m0 + r < p.M) p.mean_out[m] = mu + (p.ln_shift ? p.ln_shift[m] : 0.f);
+            // (relative mean, rstd) of the rows for ser_attention's in-kernel WavLM gate, which normalises the same operand copy
+            if (p.lnstat_out && nt == 0 && g == 0 && m0 + r < p.M) *(f32x2*)(p.lnstat_out + 2 * (int64_t)m) = (f32x2){mu, lnst[2 * r + 1]};
         }
         __syncthreads();
     }
@@ -816,6 +818,7 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         return ser_fail(-15, "ser_gemm: stat_out needs stat_groups >= groups*ceil(N/64) and no fused-LN epilogue");
     if (a->shift_out && (!a->stat_out || a->ln_gamma)) return ser_fail(-19, "ser_gemm: shift_out needs stat_out and no fused-LN epilogue");
     if (a->mean_out && !a->ln_stats_in) return ser_fail(-20, "ser_gemm: mean_out needs ln_stats_in");
+    if (a->lnstat_out && !a->ln_stats_in) return ser_fail(-20, "ser_gemm: lnstat_out needs ln_stats_in");
     if (a->out_mode && a->out_mode != a->mode && !a->ln_gamma &&
         !((a->mode == SER_MODE_FP32X && a->out_mode == SER_MODE_FP16) || (a->mode == SER_MODE_FP16 && a->out_mode == SER_MODE_FP16X) ||
           (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16)))

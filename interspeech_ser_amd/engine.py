@@ -52,6 +52,12 @@ _NO_SHIFT = _os.environ.get("SER_NO_SHIFT", "0") == "1"
 # 12 column tiles of 256 wide instead of 13 (N = 3D + 32).  Measured (round 3, two A/B pairs): bf16 1 941 / 1 940 -> 1 933 / 1 937 utt/s,
 # f16a 1 103 -> 1 098: the extra launch (its own deferred-LayerNorm prologue, 63 blocks) costs what the 13th tile column does.  Default 0.
 _SPLIT_GATE = _os.environ.get("SER_SPLIT_GATE", "0") == "1"
+# WavLM's gate pre-activations: 2H extra columns of the packed projection (rounds 1-3: a 13th 256-wide column tile for 32 columns), or
+# computed by ser_attention from the layer input's operand copy (ser_attention_args.gate_x).  Measured on the step (tools/gate_in_attn_ab.sh,
+# two A/B pairs, one box): bf16 2 071 / 2 072 -> 2 063 / 2 061 utt/s (the kernel's latency-bound prologue pays more than the 32 single-product
+# tiles cost), f16a 1 144 / 1 149 -> 1 160 / 1 163 (there the 13th tile column is a 3-product one).  Hence "auto": in the kernel exactly when
+# the packed projection runs on two planes.  SER_GATE_IN_ATTN=0 / 1 forces either form (A/B knob).
+_GATE_IN_ATTN = _os.environ.get("SER_GATE_IN_ATTN", "auto")
 # A/B knob: SER_STEM_F16X=0 puts the stem of the f16 / f16q / f16a modes back on bf16 hi + lo planes (rounds 2 / early 3)
 _STEM_F16X = _os.environ.get("SER_STEM_F16X", "1") == "1"
 
@@ -277,7 +283,8 @@ class _EncoderBase:
               residual=None, ldr=0, res_row_mod=0, out_f32=None, ldo_f32=0, out_act: Optional[Act] = None,
               out_rowmap=None, a_ptr_offset=0, k_algo=None, ln=None, ln_eps=1e-5, tile_cfg=0,
               ln_stats=None, ln_groups=0, stat_out=None, stat_groups=0, f32_col_begin=0,
-              col_scale=1.0, col_scale_end=0, shift=None, ln_mean=None, stem=False, out_mode=0, mode=None, out_col=0):
+              col_scale=1.0, col_scale_end=0, shift=None, ln_mean=None, stem=False, out_mode=0, mode=None, out_col=0,
+              lnstat_out=None):
         rec = self._rec
         g = rec.slot("gemm") if rec is not None else GemmArgs()
         g.A = a.ptr + a_ptr_offset
@@ -318,6 +325,7 @@ class _EncoderBase:
             g.shift_in, g.shift_out, g.shift_const = _ptr(s_in), s_out.data_ptr(), float(s_const)
         if ln_mean is not None:                 # consumer side: (shift of the A rows, absolute row mean out)
             g.ln_shift, g.mean_out = _ptr(ln_mean[0]), ln_mean[1].data_ptr()
+        g.lnstat_out = _ptr(lnstat_out)         # (relative mean, rstd) of the A rows for the attention kernel's in-kernel gate
         if rec is not None:
             rec.commit(_lib.OP_GEMM, g, M=M)
             return
@@ -371,33 +379,44 @@ class _EncoderBase:
                                  shift.data_ptr(), self.x_mode, rows, D, self._s()), "ser_row_center")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
-                   gru_const=None, key_lens=None, bias2d=None):
+                   gru_const=None, key_lens=None, bias2d=None, gate_in=None):
+        """``gate_in`` = (operand copy of the layer input, lnstat of the packed projection, folded weights, constants): the WavLM gate
+        is computed inside the kernel (ser_attention_args.gate_x) instead of read from gate columns of ``qkv``."""
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
         # column blocks of the packed projection: [q | k | v | gate] or, with the logit path on its own launch ("f16q"), [q | k | gate | v]
         q_col, k_col, v_col, gate_col = self._qkv_cols()
         amode = _lib.MODE_FP16Q if self.qk_mode is not None else self.attn_mode
         rec = self._rec
+        a = rec.slot("attention") if rec is not None else _lib.AttentionArgs()
+        a.qkv, a.ld, a.plane_stride = qkv.ptr, qkv.cols, qkv.plane_stride
+        a.q_col, a.k_col, a.v_col, a.B = q_col, k_col, v_col, B
+        a.frame_offs, a.table, a.gate = frame_offs_dev.data_ptr(), _ptr(table), _ptr(gate)
+        a.max_frames, a.table_T = max_frames, table_T
+        a.out, a.ldo, a.out_plane_stride = out.ptr, out.cols, out.plane_stride
+        a.H, a.dh, a.scale, a.mode, a.gate_col = H, dh, -1.0, amode, gate_col       # q is pre-scaled
+        a.gru_const, a.key_lens = _ptr(gru_const), _ptr(key_lens)
+        a.bias2d, a.bias2d_ld = _ptr(bias2d), (0 if bias2d is None else bias2d.shape[-1])
+        if gate_in is not None:
+            xa, lnstat, gw, gcb = gate_in
+            a.gate_x, a.gate_x_ld, a.gate_x_plane_stride, a.gate_x_planes = xa.ptr, xa.cols, xa.plane_stride, xa.planes
+            a.gate_stat, a.gate_w, a.gate_cb = lnstat.data_ptr(), gw.data_ptr(), gcb.data_ptr()
         if rec is not None:
-            a = rec.slot("attention")
-            a.qkv, a.ld, a.plane_stride = qkv.ptr, qkv.cols, qkv.plane_stride
-            a.q_col, a.k_col, a.v_col, a.B = q_col, k_col, v_col, B
-            a.frame_offs, a.table, a.gate = frame_offs_dev.data_ptr(), _ptr(table), _ptr(gate)
-            a.max_frames, a.table_T = max_frames, table_T
-            a.out, a.ldo, a.out_plane_stride = out.ptr, out.cols, out.plane_stride
-            a.H, a.dh, a.scale, a.mode, a.gate_col = H, dh, -1.0, amode, gate_col       # q is pre-scaled
-            a.gru_const, a.key_lens = _ptr(gru_const), _ptr(key_lens)
-            a.bias2d, a.bias2d_ld = _ptr(bias2d), (0 if bias2d is None else bias2d.shape[-1])
             rec.commit(_lib.OP_ATTENTION, a, B=B, max_frames=max_frames, table_T=table_T)
             return
-        check(lib.ser_attention(qkv.ptr, qkv.cols, qkv.plane_stride, q_col, k_col, v_col, frame_offs_dev.data_ptr(), B,
-                                max_frames, _ptr(table), table_T, _ptr(gate), out.ptr, out.cols, out.plane_stride,
-                                H, dh, -1.0, amode, gate_col, _ptr(gru_const), _ptr(key_lens), _ptr(bias2d),
-                                0 if bias2d is None else bias2d.shape[-1], self._s()),   # q is pre-scaled
-              "ser_attention")
+        check(lib.ser_attention_v(C.byref(a), self._s()), "ser_attention")
+
+    @staticmethod
+    def _gate_in(pl, lay):
+        return (pl["xa"], pl["gst"], lay["gate_w"], lay["gate_cb"]) if "gate_w" in lay else None
 
     def _gate_pad(self) -> int:
         """extra columns of the packed projection: the WavLM gate's two pre-activations per head, padded to a multiple of 8"""
-        return ((2 * self.geo.heads + 7) // 8) * 8 if self.geo.family == FAMILY_WAVLM else 0
+        return ((2 * self.geo.heads + 7) // 8) * 8 if (self.geo.family == FAMILY_WAVLM and not self._gate_in_attn()) else 0
+
+    def _gate_in_attn(self) -> bool:
+        if _GATE_IN_ATTN in ("0", "1"):
+            return _GATE_IN_ATTN == "1"
+        return self.qk_mode is not None or _PLANES[self.attn_mode] == 2
 
     def _qkv_cols(self):
         """(q, k, v, gate) first columns inside the packed projection output"""
@@ -414,14 +433,15 @@ class _EncoderBase:
         D = geo.hidden
         stats = pl["px0"] if first else pl["px"]
         scale = geo.head_dim ** -0.5 * 1.4426950408889634
+        lnstat = pl["gst"] if "gate_w" in lay else None     # (relative mean, rstd) per row for the attention kernel's in-kernel gate
         if self.qk_mode is None:
             self._gemm(pl["xa"], lay["qkv"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
-                       col_scale_end=D, ln_mean=ln_mean, mode=self.attn_mode)
+                       col_scale_end=D, ln_mean=ln_mean, mode=self.attn_mode, lnstat_out=lnstat)
             if "gate" in lay:                       # WavLM gate pre-activations: 2H columns behind v, their own narrow launch
                 self._gemm(pl["xa"], lay["gate"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], out_col=3 * D, mode=self.attn_mode)
             return
         self._gemm(pl["xa"], lay["qk"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
-                   col_scale_end=D, ln_mean=ln_mean, mode=self.qk_mode)
+                   col_scale_end=D, ln_mean=ln_mean, mode=self.qk_mode, lnstat_out=lnstat)
         self._gemm(pl["xa"], lay["v"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], out_col=self._qkv_cols()[2])
 
     @staticmethod
@@ -463,7 +483,7 @@ class _EncoderBase:
             self._qkv_gemm(pl, lay, M, i == 0, gx, (pl["sx"], pl["mx"]) if shifted else None)
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"],
-                                table_T=pl["Tmax"], gru_const=lay["gate_c"])
+                                table_T=pl["Tmax"], gru_const=lay["gate_c"], gate_in=self._gate_in(pl, lay))
             else:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
             self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D,
@@ -512,7 +532,7 @@ class _EncoderBase:
             self._qkv_gemm(pl, lay, M, i == 0, pl["first_groups"] if i == 0 else gD, (pl["sx"], pl["mx"]))
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"], table_T=pl["Tmax"],
-                                gru_const=lay["gate_c"])
+                                gru_const=lay["gate_c"], gate_in=self._gate_in(pl, lay))
             else:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
             self._gemm(pl["ctx"], lay["out"], M, residual=pl["h"], ldr=D, out_f32=pl["h"], ldo_f32=D, out_act=pl["ha"],
@@ -528,9 +548,21 @@ class _EncoderBase:
         ws = [sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]]
         bs = [sd[a + ".q_proj.bias"], kb, sd[a + ".v_proj.bias"]]
         lay = {}
+        if gate and self._gate_in_attn():
+            # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in LN1(x) restricted to the
+            # head's dh channels.  ser_attention evaluates them per query from the layer input's operand copy with the LayerNorm in
+            # closed form (ser_attention_args.gate_x): pre_j = rstd (x . (gamma w_j) - mean sum(gamma w_j)) + (beta . w_j + b_j)
+            w8, b8 = sd[a + ".gru_rel_pos_linear.weight"].double(), sd[a + ".gru_rel_pos_linear.bias"].double()
+            wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 1)                       # [dh, 2]
+            gam, bet = sd[ln1 + ".weight"].double().view(H, dh, 1), sd[ln1 + ".bias"].double().view(H, dh, 1)
+            gw = gam * wab[None]                                                        # [H, dh, 2]
+            cb = torch.cat([gw.sum(1), (bet * wab[None]).sum(1) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None]], 1)   # [H, 4]
+            lay["gate_w"] = self._dev_f32(gw.reshape(H * dh, 2).float())
+            lay["gate_cb"] = self._dev_f32(cb.float())
+            lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
+            gate = False                                                                # no gate columns in the packed projection
         if gate:
-            # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in
-            # LN1(x) -> 2H extra output columns of the packed projection; the gate kernel disappears
+            # (SER_GATE_IN_ATTN=0) the two pre-activations per head as 2H extra output columns of the packed projection
             w8, b8 = sd[a + ".gru_rel_pos_linear.weight"].float(), sd[a + ".gru_rel_pos_linear.bias"].float()
             wa, wb = w8[:4].sum(0), w8[4:].sum(0)
             wg = torch.zeros(2 * H, D, device=wdev)
@@ -574,6 +606,7 @@ class _EncoderBase:
         pl["sh"] = torch.zeros(M, dtype=torch.float32, device=dev)       # row shift of the ha copy / ph partials
         pl["mx"] = torch.zeros(M, dtype=torch.float32, device=dev)       # absolute row mean of x (written by the QKV GEMM)
         pl["mh"] = torch.zeros(M, dtype=torch.float32, device=dev)       # absolute row mean of h (written by the FC1 GEMM)
+        pl["gst"] = torch.zeros((M, 2), dtype=torch.float32, device=dev)  # (relative mean, rstd) of x's rows (packed projection -> attention's gate)
         pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
         pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
         pl["qkv"] = self._new_act(M, nqkv, mode=self.x_mode)      # "f16q": q, k, gate columns carry a lo plane, v's stays unused

@@ -709,6 +709,94 @@ def test_attention_fused_gate_columns(L, mode):
     assert err < mode_tol(mode, 3e-2, 1e-4), err
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("dh,H", [(64, 2), (64, 16), (32, 3)])
+def test_attention_gate_from_operand_copy(L, mode, dh, H):
+    """ser_attention_v with gate_x: the WavLM gate's two pre-activations per (row, head) are computed INSIDE the kernel from the layer
+    input's operand copy, (relative mean, rstd) per row and the LayerNorm-folded weights (HF modeling_wavlm.py:167-180 on
+    LayerNorm1(x)) -- against an fp64 statement of LayerNorm -> Linear(dh, 8) -> sums of four -> sigmoids."""
+    Ts = [90, 200, 37]
+    D, M, Tmax = H * dh, sum(Ts), 200
+    g = torch.Generator().manual_seed(dh + H)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    qkv[:, : 2 * D] *= 1.5
+    qa = to_act(qkv, mode)
+    qv = act_value(qa).cpu().double()
+    x = torch.randn(M, D, generator=g) * 2.0 + torch.randn(M, 1, generator=g)          # layer input; rows with their own offsets
+    xa = to_act(x, mode)
+    xv = act_value(xa).cpu().double()                                                   # what the kernel reads
+    gam, bet = torch.rand(D, generator=g).double() + 0.5, torch.randn(D, generator=g).double() * 0.2
+    w8, b8 = torch.randn(8, dh, generator=g).double() * 0.3, torch.randn(8, generator=g).double() * 0.2
+    cst = torch.randn(H, generator=g) + 1.0
+    table = torch.randn(H, 2 * Tmax - 1, generator=g)
+    mu, var = xv.mean(1, keepdim=True), xv.var(1, unbiased=False, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    ln = ((xv - mu) * rstd * gam + bet).view(M, H, dh)
+    pre8 = ln @ w8.T + b8                                                               # [M, H, 8]
+    a, bsg = torch.sigmoid(pre8[..., :4].sum(-1)), torch.sigmoid(pre8[..., 4:].sum(-1))
+    gate = a * (bsg * cst.double()[None, :] - 1.0) + 2.0
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    ref = torch.empty(M, D, dtype=torch.float64)
+    for b, T in enumerate(Ts):
+        blk = qv[offs[b]:offs[b + 1]]
+        q, k, v = (blk[:, i * D:(i + 1) * D].view(T, H, dh).permute(1, 0, 2) for i in range(3))
+        c = Tmax - 1
+        o = attention_reference(q, k, v, dh ** -0.5, table[:, c - (T - 1): c + T].double(), gate[offs[b]:offs[b + 1]])
+        ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
+    # host side of the fold (engine._layer_weights)
+    wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 1)                                # [dh, 2]
+    gw = gam.view(H, dh, 1) * wab[None]
+    cb = torch.cat([gw.sum(1), (bet.view(H, dh, 1) * wab[None]).sum(1) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None]], 1)
+    gwd, cbd = gw.reshape(H * dh, 2).float().contiguous().to(DEV), cb.float().contiguous().to(DEV)
+    std = torch.cat([mu, rstd], 1).float().contiguous().to(DEV)
+    planes = 2 if mode == 2 else 1
+    out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    td, cd = table.to(DEV), cst.to(DEV)
+    a_ = L.AttentionArgs()
+    a_.qkv, a_.ld, a_.plane_stride, a_.q_col, a_.k_col, a_.v_col, a_.B = qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, len(Ts)
+    a_.frame_offs, a_.table, a_.max_frames, a_.table_T = foffs.data_ptr(), td.data_ptr(), Tmax, Tmax
+    a_.out, a_.ldo, a_.out_plane_stride, a_.H, a_.dh, a_.scale, a_.mode = out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode
+    a_.gru_const = cd.data_ptr()
+    a_.gate_x, a_.gate_x_ld, a_.gate_x_plane_stride, a_.gate_x_planes = xa.data_ptr(), D, M * D, planes
+    a_.gate_stat, a_.gate_w, a_.gate_cb = std.data_ptr(), gwd.data_ptr(), cbd.data_ptr()
+    L.check(L.lib.ser_attention_v(C.byref(a_), stream()), "ser_attention_v")
+    torch.cuda.synchronize()
+    err = (act_value(out).cpu().double() - ref).abs().max().item()
+    assert err < mode_tol(mode, 3e-2, 1e-4), err
+    a_.gate_w = None                                                                    # incomplete gate_x arguments are refused
+    assert L.lib.ser_attention_v(C.byref(a_), stream()) != 0
+
+
+def test_gemm_reports_row_statistics_for_the_gate(L):
+    """ser_gemm_args.lnstat_out: the consumer of a deferred LayerNorm writes (mean relative to the rows' shift, rstd) per row --
+    the numbers ser_attention's in-kernel gate applies to the same operand copy."""
+    M, N, K = 300, 128, 256
+    g = torch.Generator().manual_seed(3)
+    shift = torch.randn(M, generator=g) * 3.0
+    xc = torch.randn(M, K, generator=g) * 1.5 + 0.3                                      # rows as stored: x - shift
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    groups = K // 64
+    part = torch.stack([xc.view(M, groups, 64).sum(-1), (xc.view(M, groups, 64) ** 2).sum(-1)], -1).contiguous()   # [M, groups, 2]
+    Aa, Wa = to_act(xc, 1), to_act(W, 1)
+    ga = L.GemmArgs()
+    out = torch.empty(M, N, device=DEV)
+    lnst = torch.zeros(M, 2, device=DEV)
+    mean_abs = torch.zeros(M, device=DEV)
+    pd, sd_, cs = part.to(DEV), shift.to(DEV), act_value(Wa).sum(1).contiguous()
+    ga.A, ga.lda, ga.W, ga.M, ga.N, ga.K, ga.groups, ga.mode = Aa.data_ptr(), K, Wa.data_ptr(), M, N, K, 1, 1
+    ga.out_f32, ga.ldo_f32 = out.data_ptr(), N
+    ga.ln_stats_in, ga.ln_groups, ga.ln_colsum, ga.ln_eps = pd.data_ptr(), groups, cs.data_ptr(), 1e-5
+    ga.ln_shift, ga.mean_out, ga.lnstat_out = sd_.data_ptr(), mean_abs.data_ptr(), lnst.data_ptr()
+    L.check(L.lib.ser_gemm(C.byref(ga), stream()), "ser_gemm")
+    torch.cuda.synchronize()
+    mu = xc.double().mean(1)
+    rstd = 1.0 / torch.sqrt(xc.double().var(1, unbiased=False) + 1e-5)
+    assert (lnst[:, 0].cpu().double() - mu).abs().max() < 1e-5
+    assert ((lnst[:, 1].cpu().double() - rstd) / rstd).abs().max() < 1e-5
+    assert (mean_abs.cpu().double() - (mu + shift.double())).abs().max() < 1e-5
+
+
 def _prescaled_case(L, mode, dh, bias, Ts, ramp=0.0):
     H = 2
     D, M = H * dh, sum(Ts)
