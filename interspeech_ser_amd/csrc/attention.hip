@@ -276,15 +276,16 @@ void attention_kernel(const AttnParams p) {
             g_in0 = p.gate[(int64_t)(row0 + qc) * p.H + h];
         } else if (p.gx) {
             const unsigned short* xr = p.gx + (int64_t)(row0 + qc) * p.gx_ld + h * dh;
+            const unsigned short* xl = xr + (p.gx_planes == 2 ? p.gx_plane : 0);      // no lo plane: the hi one again, weighted 0 below
             const float* wr = p.gw + (int64_t)h * dh * 2;
 #pragma unroll
-            for (int i = 0; i < GCH; ++i) {
-                const int d = (2 * i + hh) * 8;
-                const bool on = d < dh;
-                gxv[0][i] = on ? *(const u32x4*)(xr + d) : (u32x4){0u, 0u, 0u, 0u};
-                gxv[1][i] = (on && p.gx_planes == 2) ? *(const u32x4*)(xr + p.gx_plane + d) : (u32x4){0u, 0u, 0u, 0u};
+            for (int i = 0; i < GCH; ++i) {                          // unconditional loads from valid addresses (a guarded load costs hipcc a
+                const int d = (2 * i + hh) * 8;                      // branch and a vmcnt(0) each: f16a step 1 156 -> 1 169 utt/s without
+                const int dd = d < dh ? d : 0;                       // them); chunks past dh re-read chunk 0, weighted 0
+                gxv[0][i] = *(const u32x4*)(xr + dd);
+                gxv[1][i] = *(const u32x4*)(xl + dd);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gwv[i][j] = on ? *(const f32x4*)(wr + 2 * d + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) gwv[i][j] = *(const f32x4*)(wr + 2 * dd + 4 * j);
             }
             gst = *(const f32x2*)(p.gstat + 2 * (int64_t)(row0 + qc));
             g_c = p.gru_const[h];
@@ -319,9 +320,10 @@ void attention_kernel(const AttnParams p) {
             for (int i = 0; i < GCH; ++i) {
                 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
                 const u16x8 eh = __builtin_bit_cast(u16x8, gxv[0][i]), el = __builtin_bit_cast(u16x8, gxv[1][i]);
+                const float on = ((2 * i + hh) * 8 < dh) ? 1.f : 0.f, lo_on = p.gx_planes == 2 ? on : 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float x = elem2f<MODE>(eh[e]) + elem2f<MODE>(el[e]);      // lo plane: zeros when there is none
+                    const float x = fmaf(elem2f<MODE>(el[e]), lo_on, elem2f<MODE>(eh[e]) * on);
                     da = fmaf(x, gwv[i][e >> 1][2 * (e & 1)], da);
                     db = fmaf(x, gwv[i][e >> 1][2 * (e & 1) + 1], db);
                 }

@@ -52,12 +52,12 @@ _NO_SHIFT = _os.environ.get("SER_NO_SHIFT", "0") == "1"
 # 12 column tiles of 256 wide instead of 13 (N = 3D + 32).  Measured (round 3, two A/B pairs): bf16 1 941 / 1 940 -> 1 933 / 1 937 utt/s,
 # f16a 1 103 -> 1 098: the extra launch (its own deferred-LayerNorm prologue, 63 blocks) costs what the 13th tile column does.  Default 0.
 _SPLIT_GATE = _os.environ.get("SER_SPLIT_GATE", "0") == "1"
-# WavLM's gate pre-activations: 2H extra columns of the packed projection (rounds 1-3: a 13th 256-wide column tile for 32 columns), or
-# computed by ser_attention from the layer input's operand copy (ser_attention_args.gate_x).  Measured on the step (tools/gate_in_attn_ab.sh,
-# two A/B pairs, one box): bf16 2 071 / 2 072 -> 2 063 / 2 061 utt/s (the kernel's latency-bound prologue pays more than the 32 single-product
-# tiles cost), f16a 1 144 / 1 149 -> 1 160 / 1 163 (there the 13th tile column is a 3-product one).  Hence "auto": in the kernel exactly when
-# the packed projection runs on two planes.  SER_GATE_IN_ATTN=0 / 1 forces either form (A/B knob).
-_GATE_IN_ATTN = _os.environ.get("SER_GATE_IN_ATTN", "auto")
+# WavLM's gate pre-activations: computed by ser_attention from the layer input's operand copy (ser_attention_args.gate_x; default), or
+# 2H extra columns of the packed projection (SER_GATE_IN_ATTN=0, rounds 1-3: a 13th 256-wide column tile for 32 columns).  Measured on the
+# step (tools/gate_in_attn_ab.sh, two A/B pairs per build, one box; profiles/r03_gate_in_attn_ab.txt): bf16 2 018 / 2 018 -> 2 029 / 2 029
+# utt/s, f16a 1 134 / 1 135 -> 1 154 / 1 159 (there the 13th tile column is a 3-product one).  The first form of the kernel side guarded its
+# loads (a branch and a vmcnt(0) each in hipcc's output) and LOST 0.4 % in bf16: the prologue of ser_attention is latency-bound.
+_GATE_IN_ATTN = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1"
 # A/B knob: SER_STEM_F16X=0 puts the stem of the f16 / f16q / f16a modes back on bf16 hi + lo planes (rounds 2 / early 3)
 _STEM_F16X = _os.environ.get("SER_STEM_F16X", "1") == "1"
 
@@ -411,12 +411,7 @@ class _EncoderBase:
 
     def _gate_pad(self) -> int:
         """extra columns of the packed projection: the WavLM gate's two pre-activations per head, padded to a multiple of 8"""
-        return ((2 * self.geo.heads + 7) // 8) * 8 if (self.geo.family == FAMILY_WAVLM and not self._gate_in_attn()) else 0
-
-    def _gate_in_attn(self) -> bool:
-        if _GATE_IN_ATTN in ("0", "1"):
-            return _GATE_IN_ATTN == "1"
-        return self.qk_mode is not None or _PLANES[self.attn_mode] == 2
+        return ((2 * self.geo.heads + 7) // 8) * 8 if (self.geo.family == FAMILY_WAVLM and not _GATE_IN_ATTN) else 0
 
     def _qkv_cols(self):
         """(q, k, v, gate) first columns inside the packed projection output"""
@@ -548,7 +543,7 @@ class _EncoderBase:
         ws = [sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]]
         bs = [sd[a + ".q_proj.bias"], kb, sd[a + ".v_proj.bias"]]
         lay = {}
-        if gate and self._gate_in_attn():
+        if gate and _GATE_IN_ATTN:
             # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in LN1(x) restricted to the
             # head's dh channels.  ser_attention evaluates them per query from the layer input's operand copy with the LayerNorm in
             # closed form (ser_attention_args.gate_x): pre_j = rstd (x . (gamma w_j) - mean sum(gamma w_j)) + (beta . w_j + b_j)
