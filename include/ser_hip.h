@@ -302,15 +302,17 @@ typedef struct ser_attention_args {
     const float* bias2d; int64_t bias2d_ld;
     /* WavLM gate computed INSIDE the kernel (round 3; ser_attention_v only): the two pre-activations per (row, head) are linear in
      * LayerNorm1(x) restricted to the head's dh channels (HF modeling_wavlm.py:167-180), so instead of riding along as 2H extra output
-     * columns of the packed projection (gate_col: a 13th 256-wide column tile for 32 columns at D = 1024) every query reads its own dh
-     * elements of the layer input's operand copy and applies the deferred LayerNorm in closed form:
-     *   pre_j = rstd * (sum_d x[d] * gate_w[h*dh + d][j] - mean * gate_cb[h][j]) + gate_cb[h][2 + j],   j = 0, 1
-     * gate_x = that copy (the A operand of the packed projection, element type of `mode`, gate_x_planes planes), gate_stat = the
-     * projection's ser_gemm_args.lnstat_out, gate_w = gamma-folded summed weights, gate_cb = (column sums | beta W^T + b).  Needs table
-     * and gru_const; gate and gate_col are ignored. */
+     * columns of the packed projection (gate_col: a 13th 256-wide column tile for 32 columns at D = 1024) every query block multiplies
+     * its rows' dh elements of the layer input's operand copy with the head's two folded weight rows on the matrix cores (one MFMA chain
+     * shaped like S = K Q^T) and applies the deferred LayerNorm in closed form:
+     *   pre_j = rstd * (sum_d x[d] * gate_w[h][j][d] - mean * gate_cb[h][j]) + gate_cb[h][2 + j],   j = 0, 1
+     * gate_x = that copy (the A operand of the packed projection: element type and plane count of `mode`), gate_stat = the projection's
+     * ser_gemm_args.lnstat_out, gate_w = gamma-folded summed weights as operand planes [planes][H][2][dh] in the same format (ser_split_bf16),
+     * gate_cb = fp32 [H][4] (column sums of the fp32 fold | beta W^T + b).  Needs table and gru_const; gate and gate_col are ignored. */
     const void* gate_x; int64_t gate_x_ld; int64_t gate_x_plane_stride;
-    const float* gate_stat; const float* gate_w; const float* gate_cb;
+    const float* gate_stat; const void* gate_w; const float* gate_cb;
     int32_t gate_x_planes, reserved1;
+    int64_t gate_w_plane_stride;
 } ser_attention_args;
 /* ser_attention with its arguments in a struct (the form command lists carry); the only entry point that takes the gate_x fields. */
 int ser_attention_v(const ser_attention_args* args, void* stream);

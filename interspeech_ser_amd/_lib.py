@@ -65,7 +65,7 @@ class AttentionArgs(C.Structure):
         ("bias2d", c_void_p), ("bias2d_ld", c_i64),
         ("gate_x", c_void_p), ("gate_x_ld", c_i64), ("gate_x_plane_stride", c_i64),
         ("gate_stat", c_void_p), ("gate_w", c_void_p), ("gate_cb", c_void_p),
-        ("gate_x_planes", C.c_int32), ("reserved1", C.c_int32),
+        ("gate_x_planes", C.c_int32), ("reserved1", C.c_int32), ("gate_w_plane_stride", c_i64),
     ]
 
 

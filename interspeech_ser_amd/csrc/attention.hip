@@ -48,7 +48,8 @@ struct AttnParams {
     int64_t gx_ld, gx_plane;
     int gx_planes;
     const float* gstat;        // [rows][2] relative mean, rstd (ser_gemm lnstat_out)
-    const float* gw;           // [H*dh][2]
+    const unsigned short* gw;  // [planes][H][2][dh] folded weights in the operand format of `mode`
+    int64_t gw_plane;
     const float* gcb;          // [H][4]
     unsigned short* out;
     int64_t ldo, out_plane;
@@ -265,28 +266,30 @@ void attention_kernel(const AttnParams p) {
             }
     }
     float g_in0 = 0.f, g_in1 = 0.f, g_c = 0.f;                     // raw gate inputs (consumed after the bias copy)
-    // in-kernel gate: this half-wave's 8-element chunks (c = 2 i + hh) of the query row's head slice of the layer input, both planes,
-    // and the matching rows of the folded weights; requested here, multiplied after the bias copy
-    constexpr int GCH = TBL ? DHP / 16 : 1;
-    u32x4 gxv[2][GCH];
-    f32x4 gwv[GCH][4];
+    // in-kernel gate: one MFMA chain per query block, shaped like S = K Q^T with the two folded weight rows of the head in the place of the
+    // keys (row r of the "key" operand = weight row r & 1, so EVERY lane finds pre-activation a in accumulator 0 and b in accumulator 1) and
+    // the query rows' head slice of the layer input in the place of Q.  Fragments are requested here, multiplied after the bias copy.
+    // (First form: 128 FMAs per lane on fp32 weights -- 21 vector loads per lane instead of 9, +3.3 us on the 16-utterance launch: the
+    // prologue's vector-memory INSTRUCTIONS are what it costs, 16 cycles of the texture-address path each.)
+    bf16x8 gxf[NP][KS], gwf[NP][KS];
     f32x2 gst = {0.f, 1.f};
     if (TBL) {
         if (p.gate) {
             g_in0 = p.gate[(int64_t)(row0 + qc) * p.H + h];
         } else if (p.gx) {
             const unsigned short* xr = p.gx + (int64_t)(row0 + qc) * p.gx_ld + h * dh;
-            const unsigned short* xl = xr + (p.gx_planes == 2 ? p.gx_plane : 0);      // no lo plane: the hi one again, weighted 0 below
-            const float* wr = p.gw + (int64_t)h * dh * 2;
+            const unsigned short* wr = p.gw + ((int64_t)h * 2 + (l31 & 1)) * dh;
 #pragma unroll
-            for (int i = 0; i < GCH; ++i) {                          // unconditional loads from valid addresses (a guarded load costs hipcc a
-                const int d = (2 * i + hh) * 8;                      // branch and a vmcnt(0) each: f16a step 1 156 -> 1 169 utt/s without
-                const int dd = d < dh ? d : 0;                       // them); chunks past dh re-read chunk 0, weighted 0
-                gxv[0][i] = *(const u32x4*)(xr + dd);
-                gxv[1][i] = *(const u32x4*)(xl + dd);
+            for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gwv[i][j] = *(const f32x4*)(wr + 2 * dd + 4 * j);
-            }
+                for (int ks = 0; ks < KS; ++ks) {                    // unconditional loads from valid addresses (a guarded load costs hipcc a
+                    const int d = ks * 16 + hh * 8;                  // branch and a vmcnt(0) each); chunks past dh re-read chunk 0 and the
+                    const int dd = d < dh ? d : 0;                   // activation side is zeroed
+                    u32x4 xv = *(const u32x4*)(xr + pl * p.gx_plane + dd);
+                    if (d >= dh) xv = (u32x4){0u, 0u, 0u, 0u};
+                    gxf[pl][ks] = __builtin_bit_cast(bf16x8, xv);
+                    gwf[pl][ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(wr + pl * p.gw_plane + dd));
+                }
             gst = *(const f32x2*)(p.gstat + 2 * (int64_t)(row0 + qc));
             g_c = p.gru_const[h];
         } else {
@@ -315,25 +318,18 @@ void attention_kernel(const AttnParams p) {
     float gq2 = 0.f;
     if (TBL) {
         if (!p.gate && p.gx) {
-            float da = 0.f, db = 0.f;
+            f32x16 ga;
 #pragma unroll
-            for (int i = 0; i < GCH; ++i) {
-                typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
-                const u16x8 eh = __builtin_bit_cast(u16x8, gxv[0][i]), el = __builtin_bit_cast(u16x8, gxv[1][i]);
-                const float on = ((2 * i + hh) * 8 < dh) ? 1.f : 0.f, lo_on = p.gx_planes == 2 ? on : 0.f;
+            for (int r = 0; r < 16; ++r) ga[r] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x = fmaf(elem2f<MODE>(el[e]), lo_on, elem2f<MODE>(eh[e]) * on);
-                    da = fmaf(x, gwv[i][e >> 1][2 * (e & 1)], da);
-                    db = fmaf(x, gwv[i][e >> 1][2 * (e & 1) + 1], db);
+            for (int ks = 0; ks < KS; ++ks) {
+                if (NP == 2) {                                       // same product order as S: lo * hi, hi * lo, hi * hi
+                    ga = mfma32<MODE>(gwf[NP - 1][ks], gxf[0][ks], ga);
+                    ga = mfma32<MODE>(gwf[0][ks], gxf[NP - 1][ks], ga);
                 }
+                ga = mfma32<MODE>(gwf[0][ks], gxf[0][ks], ga);
             }
-            {   // the other half-wave multiplied the other chunks of the same query row
-                const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(da), __float_as_uint(da), false, false);
-                const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(db), __float_as_uint(db), false, false);
-                da = __uint_as_float(sa[0]) + __uint_as_float(sa[1]);
-                db = __uint_as_float(sb[0]) + __uint_as_float(sb[1]);
-            }
+            const float da = ga[0], db = ga[1];
             const f32x4 cb = *(const f32x4*)(p.gcb + 4 * h);
             g_in0 = fmaf(gst[1], da - gst[0] * cb[0], cb[2]);           // deferred LayerNorm 1 in closed form (ser_hip.h)
             g_in1 = fmaf(gst[1], db - gst[0] * cb[1], cb[3]);
@@ -715,8 +711,9 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     if (args->gate_x) {
         if (!table || !gru_const || gate || !args->gate_stat || !args->gate_w || !args->gate_cb)
             return ser_fail(-13, "ser_attention: gate_x needs table, gru_const, gate_stat, gate_w, gate_cb and no gate[]");
-        if ((args->gate_x_ld % 8) || (args->gate_x_plane_stride % 8) || args->gate_x_planes < 1 || args->gate_x_planes > 2)
-            return ser_fail(-13, "ser_attention: gate_x pitch / planes");
+        const int np_ = (args->mode == SER_MODE_FP32X || args->mode == SER_MODE_FP16X || args->mode == SER_MODE_FP16Q) ? 2 : 1;
+        if ((args->gate_x_ld % 8) || (args->gate_x_plane_stride % 8) || (args->gate_w_plane_stride % 8) || args->gate_x_planes != np_ || (args->dh % 8))
+            return ser_fail(-13, "ser_attention: gate_x / gate_w pitch, or gate_x_planes != the planes of mode %d", args->mode);
     }
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
@@ -761,7 +758,8 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     p.frame_offs = frame_offs; p.key_lens = key_lens; p.table = table; p.table_T = table_T; p.gate = gate;
     p.gru_const = gru_const; p.gate_col = gate_col;
     p.gx = (const unsigned short*)args->gate_x; p.gx_ld = args->gate_x_ld; p.gx_plane = args->gate_x_plane_stride;
-    p.gx_planes = args->gate_x_planes; p.gstat = args->gate_stat; p.gw = args->gate_w; p.gcb = args->gate_cb;
+    p.gx_planes = args->gate_x_planes; p.gstat = args->gate_stat; p.gw = (const unsigned short*)args->gate_w; p.gw_plane = args->gate_w_plane_stride;
+    p.gcb = args->gate_cb;
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
     p.bias2d = bias2d; p.b2d_ld = bias2d_ld; p.b2d_T = max_frames;

@@ -400,6 +400,7 @@ class _EncoderBase:
             xa, lnstat, gw, gcb = gate_in
             a.gate_x, a.gate_x_ld, a.gate_x_plane_stride, a.gate_x_planes = xa.ptr, xa.cols, xa.plane_stride, xa.planes
             a.gate_stat, a.gate_w, a.gate_cb = lnstat.data_ptr(), gw.data_ptr(), gcb.data_ptr()
+            a.gate_w_plane_stride = gw.shape[1] * gw.shape[2]
         if rec is not None:
             rec.commit(_lib.OP_ATTENTION, a, B=B, max_frames=max_frames, table_T=table_T)
             return
@@ -548,12 +549,15 @@ class _EncoderBase:
             # head's dh channels.  ser_attention evaluates them per query from the layer input's operand copy with the LayerNorm in
             # closed form (ser_attention_args.gate_x): pre_j = rstd (x . (gamma w_j) - mean sum(gamma w_j)) + (beta . w_j + b_j)
             w8, b8 = sd[a + ".gru_rel_pos_linear.weight"].double(), sd[a + ".gru_rel_pos_linear.bias"].double()
-            wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 1)                       # [dh, 2]
-            gam, bet = sd[ln1 + ".weight"].double().view(H, dh, 1), sd[ln1 + ".bias"].double().view(H, dh, 1)
-            gw = gam * wab[None]                                                        # [H, dh, 2]
-            cb = torch.cat([gw.sum(1), (bet * wab[None]).sum(1) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None]], 1)   # [H, 4]
-            lay["gate_w"] = self._dev_f32(gw.reshape(H * dh, 2).float())
-            lay["gate_cb"] = self._dev_f32(cb.float())
+            wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 0)                       # [2, dh]
+            gam, bet = sd[ln1 + ".weight"].double().view(H, 1, dh), sd[ln1 + ".bias"].double().view(H, 1, dh)
+            # operand planes [planes][H][2][dh] in the format the attention launch multiplies in (one MFMA chain per query block)
+            gmode = self.qk_mode if self.qk_mode is not None else self.attn_mode
+            glin = self._linear((gam * wab[None]).reshape(2 * H, dh).float(), None, mode=gmode)
+            cs = glin.w.double().sum(dim=(0, 2)).view(H, 2)                             # column sums of exactly the planes the MFMAs read
+            t = (bet * wab[None]).sum(2) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None].to(bet.device)   # beta W^T + b
+            lay["gate_w"] = glin.w
+            lay["gate_cb"] = self._dev_f32(torch.cat([cs.to(t.device), t], 1).float())
             lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
             gate = False                                                                # no gate columns in the packed projection
         if gate:

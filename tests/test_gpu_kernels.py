@@ -743,11 +743,13 @@ def test_attention_gate_from_operand_copy(L, mode, dh, H):
         c = Tmax - 1
         o = attention_reference(q, k, v, dh ** -0.5, table[:, c - (T - 1): c + T].double(), gate[offs[b]:offs[b + 1]])
         ref[offs[b]:offs[b + 1]] = o.permute(1, 0, 2).reshape(T, D)
-    # host side of the fold (engine._layer_weights)
-    wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 1)                                # [dh, 2]
-    gw = gam.view(H, dh, 1) * wab[None]
-    cb = torch.cat([gw.sum(1), (bet.view(H, dh, 1) * wab[None]).sum(1) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None]], 1)
-    gwd, cbd = gw.reshape(H * dh, 2).float().contiguous().to(DEV), cb.float().contiguous().to(DEV)
+    # host side of the fold (engine._layer_weights): operand planes [planes][H][2][dh], column sums of exactly those planes
+    wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 0)                                # [2, dh]
+    gwa = to_act((gam.view(H, 1, dh) * wab[None]).reshape(2 * H, dh).float(), mode)
+    gwv = act_value(gwa).cpu().double().view(H, 2, dh)
+    # the kernel multiplies the ROUNDED weights: the reference gate above is the exact one, so allow for that rounding below
+    cb = torch.cat([gwv.sum(2), (bet.view(H, 1, dh) * wab[None]).sum(2) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None]], 1)
+    cbd = cb.float().contiguous().to(DEV)
     std = torch.cat([mu, rstd], 1).float().contiguous().to(DEV)
     planes = 2 if mode == 2 else 1
     out = torch.zeros(planes, M, D, dtype=act_dtype(mode), device=DEV)
@@ -759,7 +761,7 @@ def test_attention_gate_from_operand_copy(L, mode, dh, H):
     a_.out, a_.ldo, a_.out_plane_stride, a_.H, a_.dh, a_.scale, a_.mode = out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode
     a_.gru_const = cd.data_ptr()
     a_.gate_x, a_.gate_x_ld, a_.gate_x_plane_stride, a_.gate_x_planes = xa.data_ptr(), D, M * D, planes
-    a_.gate_stat, a_.gate_w, a_.gate_cb = std.data_ptr(), gwd.data_ptr(), cbd.data_ptr()
+    a_.gate_stat, a_.gate_w, a_.gate_cb, a_.gate_w_plane_stride = std.data_ptr(), gwa.data_ptr(), cbd.data_ptr(), 2 * H * dh
     L.check(L.lib.ser_attention_v(C.byref(a_), stream()), "ser_attention_v")
     torch.cuda.synchronize()
     err = (act_value(out).cpu().double() - ref).abs().max().item()
