@@ -57,7 +57,7 @@ _SPLIT_GATE = _os.environ.get("SER_SPLIT_GATE", "0") == "1"
 # step (tools/gate_in_attn_ab.sh, two A/B pairs per build, one box; profiles/r03_gate_in_attn_ab.txt): bf16 2 018 / 2 018 -> 2 029 / 2 029
 # utt/s, f16a 1 134 / 1 135 -> 1 154 / 1 159 (there the 13th tile column is a 3-product one).  The first form of the kernel side guarded its
 # loads (a branch and a vmcnt(0) each in hipcc's output) and LOST 0.4 % in bf16: the prologue of ser_attention is latency-bound.
-_GATE_IN_ATTN = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1"
+# (Read when an encoder is built: _EncoderBase.gate_in_attn.)
 # A/B knob: SER_STEM_F16X=0 puts the stem of the f16 / f16q / f16a modes back on bf16 hi + lo planes (rounds 2 / early 3)
 _STEM_F16X = _os.environ.get("SER_STEM_F16X", "1") == "1"
 
@@ -212,6 +212,7 @@ class _EncoderBase:
         # planes (22-bit operands, round 3) rather than bf16 hi + lo (16-bit, the "fp32x" mode's): same cost, and the stem's share of the error
         # -- which sharp attention amplifies like any other -- drops by the 6 extra bits per operand
         self.stem_mode = (_lib.MODE_FP16X if _STEM_F16X else _lib.MODE_FP32X) if mode in ("f16", "f16q", "f16a") else self.mode
+        self.gate_in_attn = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1"    # WavLM gate inside ser_attention (see the note at the top)
         self.qk_mode = _lib.MODE_FP16X if mode == "f16q" else None             # logit path on its own launch (None: one packed launch)
         self.attn_mode = _lib.MODE_FP16X if mode == "f16a" else self.mode      # packed projection, context rows, output projection
         self.x_mode = self.qk_mode or self.attn_mode                           # format of the operand copy the packed projection reads
@@ -412,7 +413,7 @@ class _EncoderBase:
 
     def _gate_pad(self) -> int:
         """extra columns of the packed projection: the WavLM gate's two pre-activations per head, padded to a multiple of 8"""
-        return ((2 * self.geo.heads + 7) // 8) * 8 if (self.geo.family == FAMILY_WAVLM and not _GATE_IN_ATTN) else 0
+        return ((2 * self.geo.heads + 7) // 8) * 8 if (self.geo.family == FAMILY_WAVLM and not self.gate_in_attn) else 0
 
     def _qkv_cols(self):
         """(q, k, v, gate) first columns inside the packed projection output"""
@@ -544,7 +545,7 @@ class _EncoderBase:
         ws = [sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]]
         bs = [sd[a + ".q_proj.bias"], kb, sd[a + ".v_proj.bias"]]
         lay = {}
-        if gate and _GATE_IN_ATTN:
+        if gate and self.gate_in_attn:
             # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in LN1(x) restricted to the
             # head's dh channels.  ser_attention evaluates them per query from the layer input's operand copy with the LayerNorm in
             # closed form (ser_attention_args.gate_x): pre_j = rstd (x . (gamma w_j) - mean sum(gamma w_j)) + (beta . w_j + b_j)

@@ -58,6 +58,34 @@ def test_speech_golden_ragged_batch(golden_dir, mode, case):
     assert worst < TOL[mode], worst
 
 
+@pytest.mark.parametrize("mode", ["fp32x", "f16a", "bf16"])
+def test_wavlm_gate_forms_agree(golden_dir, mode, monkeypatch):
+    """The WavLM gate computed inside ser_attention (default) and read from 2H extra columns of the packed projection
+    (SER_GATE_IN_ATTN=0, the form of rounds 1-3) are the same arithmetic up to where the rounding happens: both within the
+    mode's bound of the HF states, and of each other."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_WAVLM
+    gold = np.load(os.path.join(golden_dir, "tiny_wavlm_d128h2.npz"))
+    sd = synthetic_state_dict(geo, int(gold["seed"]))
+    lengths = [int(n) for n in gold["lengths"]]
+    waves = [synth_wave(int(gold[f"wave_seed_{j}"]), n) for j, n in enumerate(lengths)]
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("SER_GATE_IN_ATTN", knob)
+        enc = SpeechEncoder(geo, sd, "cuda:0", mode=mode)
+        assert enc.gate_in_attn == (knob == "1") and (("gate_w" in enc.layers[0]) == (knob == "1"))
+        hs = enc.forward(enc.upload(waves), lengths)
+        torch.cuda.synchronize()
+        outs[knob] = hs.states.clone()
+        for j in range(len(lengths)):
+            ref = torch.from_numpy(gold[f"states_{j}"])
+            for layer in range(ref.shape[0]):
+                assert rel_err(hs.utterance(j, layer).cpu(), ref[layer]) < TOL[mode]
+    assert rel_err(outs["1"].cpu(), outs["0"].cpu()) < 2 * TOL[mode]
+
+
 STRESS = [("tiny_wavlm_outlier", "wavlm"), ("tiny_hubert_outlier", "hubert"),
           ("tiny_wavlm_rowmean", "wavlm"), ("tiny_hubert_rowmean", "hubert")]
 
