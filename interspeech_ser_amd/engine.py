@@ -549,14 +549,13 @@ class _EncoderBase:
             # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in LN1(x) restricted to the
             # head's dh channels.  ser_attention evaluates them per query from the layer input's operand copy with the LayerNorm in
             # closed form (ser_attention_args.gate_x): pre_j = rstd (x . (gamma w_j) - mean sum(gamma w_j)) + (beta . w_j + b_j)
-            w8, b8 = sd[a + ".gru_rel_pos_linear.weight"].double(), sd[a + ".gru_rel_pos_linear.bias"].double()
-            wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 0)                       # [2, dh]
-            gam, bet = sd[ln1 + ".weight"].double().view(H, 1, dh), sd[ln1 + ".bias"].double().view(H, 1, dh)
+            from .weights import fold_wavlm_gate
+            wg, t = fold_wavlm_gate(sd[a + ".gru_rel_pos_linear.weight"], sd[a + ".gru_rel_pos_linear.bias"],
+                                    sd[ln1 + ".weight"], sd[ln1 + ".bias"], H, dh)
             # operand planes [planes][H][2][dh] in the format the attention launch multiplies in (one MFMA chain per query block)
             gmode = self.qk_mode if self.qk_mode is not None else self.attn_mode
-            glin = self._linear((gam * wab[None]).reshape(2 * H, dh).float(), None, mode=gmode)
+            glin = self._linear(wg.float(), None, mode=gmode)
             cs = glin.w.double().sum(dim=(0, 2)).view(H, 2)                             # column sums of exactly the planes the MFMAs read
-            t = (bet * wab[None]).sum(2) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None].to(bet.device)   # beta W^T + b
             lay["gate_w"] = glin.w
             lay["gate_cb"] = self._dev_f32(torch.cat([cs.to(t.device), t], 1).float())
             lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))

@@ -281,6 +281,21 @@ def load_checkpoint(path: str, lora_alpha: float = 16.0) -> StateDict:
     return normalize_names(merge_lora(sd, lora_alpha))
 
 
+def fold_wavlm_gate(w8: torch.Tensor, b8: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, heads: int, head_dim: int):
+    """Load-time fold of WavLM's GRU gate (HF modeling_wavlm.py:167-180: Linear(dh -> 8) on LayerNorm1(x) per head, the eight
+    outputs summed in two fours) for ser_attention's in-kernel gate (ser_attention_args.gate_x): with the RAW layer input x of a
+    row, its mean mu and rstd,
+        pre_j[h] = rstd * (x_h . wg[2h + j] - mu * sum(wg[2h + j])) + t[h, j],      j = 0 (first four), 1 (last four)
+    Returns (wg [2H, dh] = gamma-folded summed weights, t [H, 2] = beta . w_j + b_j), both float64.  The column sums the kernel
+    subtracts are taken by the caller from the ROUNDED operand planes it uploads, like every deferred-LayerNorm GEMM's colsum."""
+    w8, b8 = w8.detach().double(), b8.detach().double()
+    wab = torch.stack([w8[:4].sum(0), w8[4:].sum(0)], 0)                               # [2, dh]
+    gam, bet = gamma.detach().double().view(heads, 1, head_dim), beta.detach().double().view(heads, 1, head_dim)
+    wg = (gam * wab[None]).reshape(2 * heads, head_dim)
+    t = (bet * wab[None]).sum(2) + torch.stack([b8[:4].sum(), b8[4:].sum()])[None]
+    return wg, t
+
+
 def state_dict_digest(sd: StateDict) -> str:
     """Order-independent checksum of a state dict (fixtures record it so a drift of
     the RNG stream between containers is detected instead of silently compared)."""

@@ -499,3 +499,33 @@ def test_pretrained_entry_points_demand_a_checkpoint():
                             "--wav_dir", "/nonexistent", "--save_path", "/nonexistent"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (script, r.stderr[-400:])
         assert "--checkpoint" in r.stdout and "Something went wrong" in r.stdout, (script, r.stdout)
+
+
+def test_wavlm_gate_fold_matches_the_oracle_gate():
+    """weights.fold_wavlm_gate (what ser_attention's in-kernel gate multiplies, ser_attention_args.gate_x) against the oracle's statement of
+    HF modeling_wavlm.py:167-180 on LayerNorm1(x): the closed form  rstd (x . wg - mu sum(wg)) + t  reproduces both pre-activation sums."""
+    import torch
+    import torch.nn.functional as F
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.weights import fold_wavlm_gate, synthetic_state_dict
+    from oracle import ssl_oracle as O
+    geo = C.TINY_WAVLM
+    sd = {k: v.double() for k, v in synthetic_state_dict(geo, 11).items()}
+    H, dh, D = geo.heads, geo.head_dim, geo.hidden
+    a = "encoder.layers.1.attention"
+    ln = "encoder.layers.1.layer_norm"
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(37, D, generator=g) * 3.0 + torch.randn(37, 1, generator=g) * 5.0).double()      # rows with their own offsets
+    wg, t = fold_wavlm_gate(sd[a + ".gru_rel_pos_linear.weight"], sd[a + ".gru_rel_pos_linear.bias"], sd[ln + ".weight"], sd[ln + ".bias"], H, dh)
+    assert wg.shape == (2 * H, dh) and t.shape == (H, 2)
+    shift = x.mean(1, keepdim=True) + 0.7                          # the operand copy is stored relative to SOME per-row shift: the form is invariant
+    xs = x - shift
+    mu = xs.mean(1, keepdim=True)
+    rstd = torch.rsqrt(xs.var(1, unbiased=False, keepdim=True) + geo.layer_norm_eps)
+    dots = torch.einsum("thd,hjd->thj", xs.view(-1, H, dh), wg.view(H, 2, dh))
+    pre = rstd[:, :, None] * (dots - mu[:, :, None] * wg.view(H, 2, dh).sum(2)[None]) + t[None]
+    aa, bb = torch.sigmoid(pre[..., 0]), torch.sigmoid(pre[..., 1])
+    gate = aa * (bb * sd[a + ".gru_rel_pos_const"].view(1, H) - 1.0) + 2.0                      # [T, H]
+    x_ln = F.layer_norm(x, (D,), sd[ln + ".weight"], sd[ln + ".bias"], geo.layer_norm_eps)
+    ref = O.wavlm_gate(geo, sd, a, x_ln)                                                       # [H, T]
+    assert (gate.T - ref).abs().max() < 1e-10
