@@ -529,3 +529,62 @@ def test_wavlm_gate_fold_matches_the_oracle_gate():
     x_ln = F.layer_norm(x, (D,), sd[ln + ".weight"], sd[ln + ".bias"], geo.layer_norm_eps)
     ref = O.wavlm_gate(geo, sd, a, x_ln)                                                       # [H, T]
     assert (gate.T - ref).abs().max() < 1e-10
+
+
+@pytest.mark.parametrize("slots", [2, 3])
+def test_pipelined_driver_loop_with_a_stubbed_model(tmp_path, capsys, slots):
+    """The pipelined form of the driver loop (submit / collect / hold over SLOTS slots, the form every GPU run takes) around a stub:
+    every file is written once with ITS batch's features, at most SLOTS - 1 batches are in flight when a new one is prepared, a slot is
+    never refilled before the batch that used it was collected, and a batch whose collect fails is retried per utterance."""
+    events = []
+
+    class Stub:
+        pipelined = True
+        SLOTS = slots
+
+        def __init__(self, args, whisper, device):
+            self.geo = C.TINY_WAVLM
+            self.weight_source = "stub"
+            self.busy = {}
+            self.n = 0
+
+        def submit(self, waves, layer_index, slot):
+            assert slot not in self.busy, "slot refilled before its batch was collected"
+            assert len(self.busy) <= self.SLOTS - 1
+            self.n += 1
+            self.busy[slot] = self.n
+            events.append(("submit", self.n, slot))
+            return dict(slot=slot, batch=self.n, lengths=[len(w) for w in waves])
+
+        def collect(self, ticket):
+            assert self.busy.pop(ticket["slot"]) == ticket["batch"]
+            events.append(("collect", ticket["batch"], ticket["slot"]))
+            if ticket["batch"] == 2:
+                raise RuntimeError("device lost this batch")
+            return [torch.full((self.geo.frames_for(n), 4), float(ticket["batch"])) for n in ticket["lengths"]]
+
+        def hold(self, slot, futures):
+            for f in futures:
+                f.result()
+
+        def extract(self, waves, layer_index):                   # the per-utterance retry of the failed batch
+            return [torch.full((self.geo.frames_for(len(w)), 4), -1.0) for w in waves]
+
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(10):
+        write_wav(wav_dir / f"u{i}.wav", 0.1 * rng.standard_normal(4000 + 100 * i))
+    out = tmp_path / "out"
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--batch_size", "2", "--use_n_layer", "--n_layer", "0"],
+                       whisper=False, extractor_factory=Stub) == 0
+    assert sorted(os.listdir(out)) == sorted(f"u{i}.pt" for i in range(10))
+    vals = [float(torch.load(str(out / f"u{i}.pt"))[0, 0]) for i in range(10)]          # two files per batch (the driver orders files by length)
+    assert sorted(vals) == [-1.0, -1.0, 1.0, 1.0, 3.0, 3.0, 4.0, 4.0, 5.0, 5.0]        # batch 2 came back through the per-utterance retry
+    for i in range(10):
+        assert torch.load(str(out / f"u{i}.pt")).shape == (C.TINY_WAVLM.frames_for(4000 + 100 * i), 4)
+    order = [e for e in events if e[0] == "collect"]
+    assert [e[1] for e in order] == [1, 2, 3, 4, 5]                                    # collected oldest first
+    first_collect = events.index(("collect", 1, 0))
+    assert [e[0] for e in events[:first_collect]].count("submit") == slots              # SLOTS batches submitted before the first wait
+    assert "10 utterances" in capsys.readouterr().out
