@@ -332,9 +332,13 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, l
         mine = [p for p in mine if not present(p)]
     batches = make_batches(mine, max(1, args.batch_size))
 
+    # decode into page-locked memory when a GPU is there: the upload is then one async copy per utterance, no packing pass on the
+    # launching thread (SER_PINNED_DECODE=0: A/B knob, the round-2 form)
+    pinned_decode = torch.cuda.is_available() and os.environ.get("SER_PINNED_DECODE", "1") == "1"
+
     def decode(path):
         try:
-            return path, load_wav_16k(path, resample=args.resample), None
+            return path, load_wav_16k(path, resample=args.resample, pinned=pinned_decode), None
         except Exception as e:                            # noqa: BLE001  (reference: except Exception -> print)
             return path, None, e
 

@@ -872,6 +872,17 @@ class SpeechEncoder(_EncoderBase):
         The copy is enqueued on the current stream; the staging buffer is reused only after an event
         recorded behind its previous copy has completed."""
         total = int(sum(len(w) for w in waves))
+        if total and all(isinstance(w, np.ndarray) and w.dtype == np.float32 and w.flags.c_contiguous for w in waves):
+            srcs = [torch.from_numpy(w) for w in waves]
+            if all(t.is_pinned() for t in srcs):
+                # every utterance already sits in page-locked memory (driver: frontend.load_wav_16k(pinned=True)): one async copy each,
+                # no packing pass here; torch's host allocator keeps a block from being re-issued until the copy from it has run
+                dev = torch.empty(total, dtype=torch.float32, device=self.device)
+                o = 0
+                for t in srcs:
+                    dev[o:o + t.numel()].copy_(t, non_blocking=True)
+                    o += t.numel()
+                return dev
         pins = self.__dict__.setdefault("_pin_in", {})
         pin, evt = pins.get(slot, (None, None))
         if pin is None or pin.numel() < total:

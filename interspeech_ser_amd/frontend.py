@@ -23,9 +23,12 @@ class UnsupportedAudio(ValueError):
     pass
 
 
-def _native_wav(path: str):
+def _native_wav(path: str, pinned: bool = False):
     """RIFF/WAVE through libserhip's ser_wav_read_f32 (plain C, runs without the GIL): (samples, rate) or None when
-    the file is not something that reader handles (the Python decoder below then gives the verdict)."""
+    the file is not something that reader handles (the Python decoder below then gives the verdict).
+    ``pinned``: decode straight into page-locked memory from torch's caching host allocator (the array keeps its block alive; the
+    allocator re-issues a block only after the copies enqueued from it have completed), so the launching thread can enqueue the
+    H2D copy of every utterance without first packing the batch into a staging buffer (engine.upload)."""
     import ctypes
     from ._lib import lib
     sr, ch = ctypes.c_int32(0), ctypes.c_int32(0)
@@ -33,14 +36,18 @@ def _native_wav(path: str):
     n = lib.ser_wav_read_f32(bpath, None, 0, ctypes.byref(sr), ctypes.byref(ch))
     if n < 0:
         return None
-    x = np.empty(int(n), dtype=np.float32)
+    if pinned and n > 0:
+        import torch
+        x = torch.empty(int(n), dtype=torch.float32, pin_memory=True).numpy()
+    else:
+        x = np.empty(int(n), dtype=np.float32)
     got = lib.ser_wav_read_f32(bpath, x.ctypes.data, int(n), None, None)
     if got != n:
         return None
     return x, int(sr.value)
 
 
-def load_wav_16k(path: str, resample: bool = False) -> np.ndarray:
+def load_wav_16k(path: str, resample: bool = False, pinned: bool = False) -> np.ndarray:
     """Decode a RIFF/WAVE file to mono float32 in [-1, 1] the way soundfile (behind
     ``librosa.load``) does: integer PCM / 2^(bits-1), channels averaged.
     16 kHz input is bit-faithful to the reference.  Other rates: the reference resamples with soxr_hq
@@ -49,7 +56,7 @@ def load_wav_16k(path: str, resample: bool = False) -> np.ndarray:
     ``resample=True`` (driver flag ``--resample``) they go through a Kaiser-windowed polyphase filter
     (``scipy.signal.resample_poly``): usable features, but PARITY UNPINNED against the reference's resampler.
     16 kHz files take the native reader (same arithmetic, no GIL); everything else the Python path below."""
-    native = _native_wav(path)
+    native = _native_wav(path, pinned)
     if native is not None and native[1] == TARGET_SR:
         return native[0]
     try:

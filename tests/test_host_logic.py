@@ -296,7 +296,7 @@ def test_opt_in_resampler_keeps_pitch_and_length(tmp_path):
 def _python_decoder(path):
     """frontend.load_wav_16k with the native reader switched off: the pure-Python statement of the same decode."""
     saved = frontend._native_wav
-    frontend._native_wav = lambda p: None
+    frontend._native_wav = lambda p, pinned=False: None
     try:
         return frontend.load_wav_16k(path)
     finally:
