@@ -36,10 +36,13 @@ def _native_wav(path: str, pinned: bool = False):
     n = lib.ser_wav_read_f32(bpath, None, 0, ctypes.byref(sr), ctypes.byref(ch))
     if n < 0:
         return None
+    x = None
     if pinned and n > 0:
-        import torch
-        x = torch.empty(int(n), dtype=torch.float32, pin_memory=True).numpy()
-    else:
+        try:
+            x = torch.empty(int(n), dtype=torch.float32, pin_memory=True).numpy()
+        except RuntimeError:                              # page-locked memory exhausted / not available: decode into pageable memory
+            x = None
+    if x is None:
         x = np.empty(int(n), dtype=np.float32)
     got = lib.ser_wav_read_f32(bpath, x.ctypes.data, int(n), None, None)
     if got != n:
