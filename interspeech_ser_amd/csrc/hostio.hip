@@ -17,14 +17,20 @@
 //   <stem>/data/0     rows*cols little-endian fp32, payload aligned to 64 bytes (extra field "FB", as torch does)
 //   <stem>/version    "3\n"
 // stored (no compression), CRC-32 of every member in its local header and in the central directory.
-#include "ser_common.h"
+// Plain C++ on purpose (no HIP header): `make asan` compiles this file and hosterr.hip with g++ -fsanitize=address,undefined into
+// the fuzz harness tests/test_host_fuzz.py drives (malformed RIFF headers, short files, huge lengths) -- no GPU needed.
+#include "../../include/ser_hip.h"
+#include <stdint.h>
 #include <errno.h>
+#include <new>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
 #include <immintrin.h>
+
+int ser_fail(int code, const char* fmt, ...);          // hosterr.hip
 
 namespace {
 
@@ -197,10 +203,11 @@ std::string pickle_f32_matrix(int64_t rows, int64_t cols) {
 
 }  // namespace
 
-extern "C" int ser_pt_write_f32(const char* path, const float* host_data, int64_t rows, int64_t cols) {
+static int pt_write_f32(const char* path, const float* host_data, int64_t rows, int64_t cols) {
     if (!path || rows < 0 || cols <= 0 || (!host_data && rows > 0)) return ser_fail(-1, "ser_pt_write_f32: bad arguments");
+    if (rows >= (1LL << 29) || cols >= (1LL << 29) || rows * cols >= (1LL << 29))       // (each factor first: the product cannot wrap)
+        return ser_fail(-2, "ser_pt_write_f32: tensor too large for a 32-bit zip member");
     const int64_t numel = rows * cols;
-    if (numel >= (1LL << 29)) return ser_fail(-2, "ser_pt_write_f32: tensor too large for a 32-bit zip member");
     // archive prefix = file stem, as torch.save names it
     std::string stem(path);
     const size_t slash = stem.find_last_of('/');
@@ -252,27 +259,34 @@ extern "C" int ser_pt_write_f32(const char* path, const float* host_data, int64_
     return 0;
 }
 
+extern "C" int ser_pt_write_f32(const char* path, const float* host_data, int64_t rows, int64_t cols) {
+    try {                                                             // no C++ exception may cross the C ABI (std::string / vector growth)
+        return pt_write_f32(path, host_data, rows, cols);
+    } catch (const std::bad_alloc&) {
+        return ser_fail(-ENOMEM, "ser_pt_write_f32: out of memory");
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- a5
 namespace {
-uint32_t rd32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
-uint32_t rd16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+uint32_t rd32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint32_t rd16(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 }  // namespace
 
 // Returns the number of frames (samples per channel) of the file, or < 0 on error (ser_last_error() says why).
 // With host_dst != NULL the mono float32 samples are written there (capacity in samples; a file with more frames
 // is an error, not a truncation).  *sample_rate / *channels receive the header values when not NULL.
 // Formats: RIFF/WAVE PCM 8/16/24/32-bit integer and 32-bit IEEE float, plain or WAVE_FORMAT_EXTENSIBLE.
-extern "C" int64_t ser_wav_read_f32(const char* path, float* host_dst, int64_t capacity, int32_t* sample_rate,
-                                    int32_t* channels) {
+static int64_t wav_read_f32(const char* path, float* host_dst, int64_t capacity, int32_t* sample_rate, int32_t* channels) {
     if (!path) return ser_fail(-1, "ser_wav_read_f32: null path");
+    if (host_dst && capacity < 0) return ser_fail(-1, "ser_wav_read_f32: negative capacity");
     FILE* f = fopen(path, "rb");
     if (!f) return ser_fail(-2, "ser_wav_read_f32: cannot open %s: %s", path, strerror(errno));
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
     unsigned char hdr[12];
-    if (fread(hdr, 1, 12, f) != 12 || memcmp(hdr, "RIFF", 4) || memcmp(hdr + 8, "WAVE", 4)) {
-        fclose(f);
+    if (fread(hdr, 1, 12, f) != 12 || memcmp(hdr, "RIFF", 4) || memcmp(hdr + 8, "WAVE", 4))
         return ser_fail(-3, "ser_wav_read_f32: %s is not a RIFF/WAVE file", path);
-    }
-    int fmt = 0, ch = 0, bits = 0, align = 0;
+    int fmt = 0, ch = 0, bits = 0;
     uint32_t sr = 0;
     int64_t data_bytes = -1;
     for (;;) {
@@ -283,51 +297,48 @@ extern "C" int64_t ser_wav_read_f32(const char* path, float* host_dst, int64_t c
             unsigned char b[40] = {0};
             const uint32_t take = len < 40 ? len : 40;
             if (len < 16 || fread(b, 1, take, f) != take) break;
-            fmt = (int)rd16(b); ch = (int)rd16(b + 2); sr = rd32(b + 4); align = (int)rd16(b + 12); bits = (int)rd16(b + 14);
+            fmt = (int)rd16(b); ch = (int)rd16(b + 2); sr = rd32(b + 4); bits = (int)rd16(b + 14);
             if (fmt == 0xFFFE && len >= 26) fmt = (int)rd16(b + 24);             // extensible: sub-format GUID starts with the tag
-            if (fseek(f, (long)(len - take) + (len & 1), SEEK_CUR) != 0) break;
+            if (fseeko(f, (off_t)(len - take) + (off_t)(len & 1), SEEK_CUR) != 0) break;
         } else if (!memcmp(ck, "data", 4)) {
             data_bytes = len;
             break;
-        } else if (fseek(f, (long)len + (len & 1), SEEK_CUR) != 0) {
+        } else if (fseeko(f, (off_t)len + (off_t)(len & 1), SEEK_CUR) != 0) {
             break;
         }
     }
-    if (data_bytes < 0 || ch <= 0 || bits <= 0) {
-        fclose(f);
+    if (data_bytes < 0 || ch <= 0 || bits <= 0)
         return ser_fail(-4, "ser_wav_read_f32: %s has no usable fmt/data chunks", path);
-    }
+    if (ch > 1024)                                                               // libsndfile's SF_MAX_CHANNELS: soundfile refuses more
+        return ser_fail(-4, "ser_wav_read_f32: %s declares %d channels", path, ch);
     const int bps = bits / 8;
     const bool is_float = fmt == 3;
-    if (!((fmt == 1 && (bps == 1 || bps == 2 || bps == 3 || bps == 4) && bits % 8 == 0) || (is_float && bps == 4))) {
-        fclose(f);
+    if (!((fmt == 1 && (bps == 1 || bps == 2 || bps == 3 || bps == 4) && bits % 8 == 0) || (is_float && bits == 32)))
         return ser_fail(-5, "ser_wav_read_f32: %s: format tag %d with %d bits is not supported", path, fmt, bits);
-    }
-    if (align <= 0) align = bps * ch;
-    {   // a streaming writer may leave 0 / 0xFFFFFFFF in the data length: trust the file size then
-        const long here = ftell(f);
-        fseek(f, 0, SEEK_END);
-        const long rest = ftell(f) - here;
-        fseek(f, here, SEEK_SET);
+    // The frame size is channels x bytes per sample, whatever the header's blockAlign field says -- what libsndfile (behind
+    // librosa.load, preprocess_speech.py:47) does for PCM / float data: it logs a mismatch and decodes with channels x width.
+    // Round 3 sized the buffer by the header's blockAlign and read channels x width bytes per frame: a header with blockAlign = 2
+    // and 60 000 channels read 120 KB past a 64-byte buffer.
+    const int64_t align = (int64_t)bps * ch;
+    {   // a streaming writer may leave 0xFFFFFFFF (or more than the file holds) in the data length: trust the file size then
+        const off_t here = ftello(f);
+        if (here < 0 || fseeko(f, 0, SEEK_END) != 0) return ser_fail(-7, "ser_wav_read_f32: cannot seek in %s", path);
+        const off_t end = ftello(f);
+        if (end < here || fseeko(f, here, SEEK_SET) != 0) return ser_fail(-7, "ser_wav_read_f32: cannot seek in %s", path);
+        const int64_t rest = (int64_t)(end - here);
         if (data_bytes == 0xFFFFFFFFLL || data_bytes > rest) data_bytes = rest;
     }
     const int64_t frames = data_bytes / align;
     if (sample_rate) *sample_rate = (int32_t)sr;
     if (channels) *channels = ch;
-    if (!host_dst) {
-        fclose(f);
-        return frames;
-    }
-    if (frames > capacity) {
-        fclose(f);
+    if (!host_dst) return frames;
+    if (frames > capacity)
         return ser_fail(-6, "ser_wav_read_f32: %s has %lld frames, buffer holds %lld", path, (long long)frames, (long long)capacity);
-    }
     std::vector<unsigned char> raw((size_t)(frames * align));
     const size_t got = raw.empty() ? 0 : fread(raw.data(), 1, raw.size(), f);
-    fclose(f);
     if (got != raw.size()) return ser_fail(-7, "ser_wav_read_f32: short read from %s", path);
     for (int64_t i = 0; i < frames; ++i) {
-        const unsigned char* p = raw.data() + i * align;
+        const unsigned char* p = raw.data() + i * align;             // ch * bps = align bytes per frame: never past raw's end
         float acc = 0.f;
         for (int c = 0; c < ch; ++c, p += bps) {
             float v;
@@ -344,4 +355,13 @@ extern "C" int64_t ser_wav_read_f32(const char* path, float* host_dst, int64_t c
         host_dst[i] = ch == 1 ? acc : acc / (float)ch;               // add, then one true division, like np.mean
     }
     return frames;
+}
+
+extern "C" int64_t ser_wav_read_f32(const char* path, float* host_dst, int64_t capacity, int32_t* sample_rate,
+                                    int32_t* channels) {
+    try {
+        return wav_read_f32(path, host_dst, capacity, sample_rate, channels);
+    } catch (const std::bad_alloc&) {
+        return ser_fail(-ENOMEM, "ser_wav_read_f32: out of memory reading %s", path ? path : "");
+    }
 }

@@ -29,7 +29,10 @@ from . import _lib
 from ._lib import GemmArgs, check, lib
 from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
-MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16}
+MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16,
+         "f16x": _lib.MODE_FP16X}
+# "f16x" (round 4): the 3-product split EVERYWHERE, like "fp32x", on fp16 hi + lo planes -- 22-bit operands instead of the 16 of the
+# bf16 pair at the same cost.  The widest margin of all modes where |values| stay inside fp16's range (65 504).
 # "f16": encoder layers on single-product fp16 operands (11 significand bits at the bf16 MFMA rate), the convolutional
 # stem -- where operand rounding hurts most and only 13 % of the FLOPs live -- on the 3-product FP32X split.
 # "f16q": "f16" with the LOGIT path of every layer fp32-grade: the q / k (+ WavLM gate) columns of the packed projection and
@@ -1164,7 +1167,7 @@ class TextEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != FAMILY_ROBERTA:
             raise ValueError("TextEncoder needs a roberta geometry")
-        if mode in ("f16", "f16q", "f16a"):
+        if mode in ("f16", "f16q", "f16a", "f16x"):
             raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
         sd = state_dict
         D = geo.hidden
@@ -1276,7 +1279,7 @@ class DebertaEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != "deberta":
             raise ValueError("DebertaEncoder needs a deberta geometry")
-        if mode in ("f16", "f16q", "f16a"):
+        if mode in ("f16", "f16q", "f16a", "f16x"):
             raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
         if geo.head_dim != 64:
             raise ValueError("DeBERTa path: head dim must be 64 (K of the position GEMMs; deberta-v3 base/large have 64)")

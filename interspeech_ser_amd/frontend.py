@@ -24,8 +24,10 @@ class UnsupportedAudio(ValueError):
 
 
 def _native_wav(path: str, pinned: bool = False):
-    """RIFF/WAVE through libserhip's ser_wav_read_f32 (plain C, runs without the GIL): (samples, rate) or None when
-    the file is not something that reader handles (the Python decoder below then gives the verdict).
+    """RIFF/WAVE through libserhip's ser_wav_read_f32 (plain C, runs without the GIL): (samples, rate), or None when the file is
+    a WAVE whose sample format that reader does not decode (the Python decoder below then gives the verdict).  A file that is not
+    RIFF/WAVE, is truncated, or whose header is inconsistent raises ``UnsupportedAudio`` with the reader's message: the driver
+    logs it as "Failed to process ..." like the reference does for any per-file error (preprocess_speech.py:46,72-73).
     ``pinned``: decode straight into page-locked memory from torch's caching host allocator (the array keeps its block alive; the
     allocator re-issues a block only after the copies enqueued from it have completed), so the launching thread can enqueue the
     H2D copy of every utterance without first packing the batch into a staging buffer (engine.upload)."""
@@ -34,8 +36,10 @@ def _native_wav(path: str, pinned: bool = False):
     sr, ch = ctypes.c_int32(0), ctypes.c_int32(0)
     bpath = os.fsencode(path)
     n = lib.ser_wav_read_f32(bpath, None, 0, ctypes.byref(sr), ctypes.byref(ch))
-    if n < 0:
+    if n == -5:                                           # a format tag / sample width the native reader does not decode
         return None
+    if n < 0:                                             # malformed, truncated or unreadable: this file's verdict ("Failed to process")
+        raise UnsupportedAudio(lib.ser_last_error().decode("utf-8", "replace"))
     x = None
     if pinned and n > 0:
         try:
@@ -45,8 +49,8 @@ def _native_wav(path: str, pinned: bool = False):
     if x is None:
         x = np.empty(int(n), dtype=np.float32)
     got = lib.ser_wav_read_f32(bpath, x.ctypes.data, int(n), None, None)
-    if got != n:
-        return None
+    if got != n:                                          # the file changed between the two passes
+        raise UnsupportedAudio(lib.ser_last_error().decode("utf-8", "replace") if got < 0 else f"{path}: frame count changed while reading")
     return x, int(sr.value)
 
 

@@ -210,7 +210,10 @@ def speech_hidden_states(geo, sd: StateDict, input_values: Tensor) -> List[Tenso
     posconv(proj) with NO LayerNorm; hs[i] = output of layer i-1; hs[L] is the
     last layer's output AFTER the encoder's final LayerNorm."""
     eps = geo.layer_norm_eps
-    feats = conv_feature_encoder(geo, sd, input_values.float())
+    # the arithmetic type follows the weights: fp32 state dicts give the reference's fp32 forward (the pinned path); a state dict
+    # cast to float64 gives the same formulas in double -- used by tests/depth_envelope.py to measure how far the fp32 reference
+    # itself sits from exact arithmetic at full depth (the conditioning of a stress case), never as the parity target
+    feats = conv_feature_encoder(geo, sd, input_values.to(sd["feature_projection.projection.weight"].dtype))
     h = feature_projection(geo, sd, feats)
     h = h + positional_conv(geo, sd, h)
     T = h.shape[0]

@@ -1,0 +1,178 @@
+"""Parity envelope of the numerics modes at FULL depth (test helper + report generator; -m gpu side of the repo).
+
+Every stress fixture under tests/golden/ is a 2-3 layer geometry.  The reference runs trained checkpoints through 24 (WavLM-large)
+or 48 (HuBERT-xlarge, XLS-R-2B) layers in fp32 (preprocessing/preprocess_speech.py:50,66,111-114), and a rounding inside the attention
+block is amplified by every later softmax, so the margin of a mode has to be measured at the depth it ships at.  This module runs
+the full geometries with the stress edits of ``weights.apply_stress`` (sharp attention, outlier channels, row-mean offsets) and a
+LoRA-scaled q / v case (r = 8, alpha = 16: preprocessing/preprocess_speech_pretrained.py:119-130) on one 10 s utterance and one
+ragged pair (3 s + 10 s), and compares all L + 1 hidden states of the HIP path with ``oracle.ssl_oracle.speech_hidden_states``.
+
+    python tests/depth_envelope.py [--models wavlm,hubert] [--modes f16a,fp32x] [--fp64] > profiles/r04_depth_envelope.txt
+
+``--fp64`` also evaluates the oracle's formulas in float64 and prints how far the fp32 REFERENCE is from that at each depth
+(the conditioning of the case: what no fp32-grade implementation can be expected to beat).  tests/test_gpu_depth.py asserts the gate.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODELS = {"wavlm": "microsoft/wavlm-large", "hubert": "facebook/hubert-xlarge-ll60k", "xlsr": "facebook/wav2vec2-xls-r-2b"}
+# "sharpF": q / k projections x F (logits x F^2); F = 4 is weights.apply_stress("sharp"), the tiny fixtures' setting
+KINDS = ("plain", "sharp2", "sharp2.5", "sharp4", "outliers", "rowmean", "lora")
+
+
+def rel_err(got, ref):
+    return float((got.double() - ref.double()).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+def clip(seed, seconds):
+    g = np.random.default_rng(seed)
+    n = int(seconds * 16000)
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    x = 0.1 * g.standard_normal(n) + 0.2 * np.sin(2 * np.pi * 220.0 * t)       # SURVEY 8d's synthetic clip: noise + a 220 Hz tone
+    return x.astype(np.float32)
+
+
+def lora_pair(geo, sd, seed=42, r=8, alpha=16.0, ratio=4.0):
+    """(oracle state dict with UN-MERGED adapters, merged state dict for the HIP path).  Adapter size: the merged q projection is
+    ~``ratio`` x its base (as tests/test_gpu_cli.py's LoRA case at the tiny geometry), v likewise."""
+    g = torch.Generator().manual_seed(seed)
+    D = geo.hidden
+    s = math.sqrt(ratio * 1.6 / math.sqrt(D) / ((alpha / r) * math.sqrt(r)))
+    ref_sd, merged = dict(sd), dict(sd)
+    ref_sd["lora_scale"] = torch.tensor(alpha / r)
+    for i in range(geo.num_layers):
+        for proj in ("q_proj", "v_proj"):
+            mod = f"encoder.layers.{i}.attention.{proj}"
+            A = torch.randn(r, D, generator=g) * s
+            B = torch.randn(D, r, generator=g) * s
+            ref_sd[mod + ".lora_A.weight"], ref_sd[mod + ".lora_B.weight"] = A, B
+            merged[mod + ".weight"] = (sd[mod + ".weight"].double() + (alpha / r) * (B.double() @ A.double())).float()
+    return ref_sd, merged
+
+
+def case_state_dicts(geo, kind, seed=0):
+    from interspeech_ser_amd.weights import apply_stress, synthetic_state_dict
+    sd = synthetic_state_dict(geo, seed)
+    if kind == "plain":
+        return sd, sd
+    if kind == "lora":
+        return lora_pair(geo, sd)
+    if kind.startswith("sharp"):
+        f = float(kind[5:] or 4.0)
+        sd = {k: v.clone() for k, v in sd.items()}
+        for i in range(geo.num_layers):
+            for proj in ("q_proj", "k_proj"):
+                for leaf in ("weight", "bias"):
+                    sd[f"encoder.layers.{i}.attention.{proj}.{leaf}"] *= f
+        return sd, sd
+    sd = apply_stress(sd, geo, kind)
+    return sd, sd
+
+
+def oracle_states(geo, ref_sd, waves, fp64=False):
+    from oracle import ssl_oracle as O              # checker only
+    out = []
+    sdx = {k: (v.double() if v.is_floating_point() else v) for k, v in ref_sd.items()} if fp64 else ref_sd
+    with torch.no_grad():
+        for w in waves:
+            out.append(O.speech_hidden_states(geo, sdx, torch.from_numpy(O.zero_mean_unit_var(w))))
+    return out
+
+
+def hip_states(geo, hip_sd, batches, mode):
+    """batches: list of lists of waveforms; one forward per batch.  Returns the per-utterance state lists in order."""
+    from interspeech_ser_amd.engine import SpeechEncoder
+    enc = SpeechEncoder(geo, hip_sd, "cuda:0", mode=mode)
+    out = []
+    for waves in batches:
+        lengths = [len(w) for w in waves]
+        hs = enc.forward(enc.upload(waves), lengths)
+        torch.cuda.synchronize()
+        for b in range(len(waves)):
+            out.append([hs.utterance(b, layer).cpu() for layer in range(len(hs))])
+    del enc
+    torch.cuda.empty_cache()
+    return out
+
+
+def envelope(model, kind, modes=("f16a", "fp32x"), fp64=False):
+    """-> {"ref64": [per-layer], mode: [per-layer worst over the three utterances]} for one (model, stress kind)."""
+    from interspeech_ser_amd import config as C
+    geo = C.geometry_for(MODELS[model])
+    ref_sd, hip_sd = case_state_dicts(geo, kind)
+    a, b, c = clip(101, 10.0), clip(102, 3.0), clip(103, 10.0)
+    batches = [[a], [b, c]]                          # one 10 s utterance alone; a ragged pair
+    flat = [a, b, c]
+    ref = oracle_states(geo, ref_sd, flat)
+    res = {}
+    if fp64:
+        ref64 = oracle_states(geo, ref_sd, flat[:1], fp64=True)
+        res["ref64"] = [rel_err(x, y) for x, y in zip(ref[0], ref64[0])]
+    outl = None
+    if kind == "outliers":
+        outl = torch.ones(geo.hidden, dtype=torch.bool)
+        outl[[7, geo.hidden - 5]] = False
+    for mode in modes:
+        got = hip_states(geo, hip_sd, batches, mode)
+        per_layer, rest = [], []
+        for layer in range(geo.num_layers + 1):
+            w = wr = 0.0
+            for u in range(3):
+                assert got[u][layer].shape == ref[u][layer].shape, (got[u][layer].shape, ref[u][layer].shape)
+                w = max(w, rel_err(got[u][layer], ref[u][layer]))
+                if outl is not None:                 # the ordinary channels on their own scale (an 800-sized outlier must not hide them)
+                    wr = max(wr, rel_err(got[u][layer][:, outl], ref[u][layer][:, outl]))
+            per_layer.append(w)
+            rest.append(wr)
+        res[mode] = per_layer
+        if fp64:                                     # against exact arithmetic, first utterance: comparable with the ref64 row
+            res[mode + ":vs64"] = [rel_err(x, y) for x, y in zip(got[0], ref64[0])]
+        if outl is not None:
+            res[mode + ":ordinary"] = rest
+    return res
+
+
+def fmt_row(name, vals, every):
+    idx = list(range(0, len(vals), every))
+    if idx[-1] != len(vals) - 1:
+        idx.append(len(vals) - 1)
+    return f"  {name:<16}" + " ".join(f"{vals[i]:.1e}" for i in idx) + f"   worst {max(vals):.2e}"
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--models", default="wavlm,hubert")
+    ap.add_argument("--kinds", default=",".join(KINDS))
+    ap.add_argument("--modes", default="f16a,fp32x")
+    ap.add_argument("--fp64", action="store_true")
+    args = ap.parse_args(argv)
+    modes = tuple(args.modes.split(","))
+    print("# error form: max|a-b| / max(1, max|b|) per hidden state, worst of {10 s alone, 3 s + 10 s ragged pair}; columns = states 0, k, 2k, ..., L")
+    print("# ref64 = the fp32 oracle against the same formulas in float64 (first utterance): the reference's own distance from exact arithmetic")
+    summary = []
+    for model in args.models.split(","):
+        for kind in args.kinds.split(","):
+            res = envelope(model, kind, modes, fp64=args.fp64)
+            L = len(next(iter(res.values())))
+            every = 4 if L <= 25 else 8
+            print(f"{MODELS[model]} ({L - 1} layers), stress = {kind}")
+            for k, v in res.items():
+                print(fmt_row(k, v, every))
+            sys.stdout.flush()
+            summary.append((model, kind, {k: max(v) for k, v in res.items()}))
+    print("# summary (worst state)")
+    for model, kind, w in summary:
+        print(f"  {model:<7}{kind:<9}" + "  ".join(f"{k} {v:.2e}" for k, v in w.items()))
+
+
+if __name__ == "__main__":
+    main()
