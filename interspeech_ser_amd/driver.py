@@ -174,7 +174,8 @@ class _Extractor:
     # end at full depth, but 5 617 / 5 239 -> 4 812 / 4 993 for the reference's default rule (stem only, host-bound) -- so
     # two slots stay the default.  What separates the end-to-end rate from the kernels' 2 015 is stream launches instead of
     # a replayed hipGraph (ragged batches change every launch's sizes), not an idle GPU: the launching thread waits.
-    SLOTS = max(2, int(os.environ.get("SER_PIPE_SLOTS", "2")))
+    # (2 or 3: the per-slot plan caches and tickets are sized for that; more slots would evict live plans every batch)
+    SLOTS = min(3, max(2, int(os.environ.get("SER_PIPE_SLOTS", "2"))))
     RUNNING = 2
 
     def submit(self, waves: List[np.ndarray], layer_index: int, slot: int):
@@ -258,6 +259,8 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, l
     disjoint writes, failure reporting -- runs without a GPU)."""
     from . import dist as D
     if local_only:
+        # _Extractor.__init__ talks to the real process group (weight broadcast): a local-only run must bring its own extractor
+        assert extractor_factory is not None, "local_only needs an extractor_factory (no collective may run on the caller's group)"
         D = _NoDist
     args = build_parser(whisper).parse_args(argv)
     rank, world, local_rank = D.env()
@@ -270,8 +273,20 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, l
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     D.init(device=torch.device("cuda", local_rank) if torch.cuda.is_available() else None)
-    # taken once on rank 0 before anybody writes: ranks must not race on len(listdir)
-    n_existing = D.broadcast_int(len(os.listdir(args.save_path)) if rank == 0 else 0)
+    # taken once on rank 0 before anybody writes: ranks must not race on len(listdir).  Outputs are written as
+    # <name>.tmp and renamed when complete; what a killed run left behind is neither a feature file nor part of the count.
+    n_existing = 0
+    if rank == 0:
+        for fn in os.listdir(args.save_path):
+            if fn.endswith((".pt.tmp", ".npy.tmp")):
+                try:
+                    os.remove(os.path.join(args.save_path, fn))
+                    print(f"Removed stale partial output {fn}")
+                except OSError:
+                    pass
+            else:
+                n_existing += 1
+    n_existing = D.broadcast_int(n_existing)
     log(f"Save path = {args.save_path} created. It has {n_existing} files in it.")
 
     wav_names = os.listdir(args.wav_dir)
@@ -311,6 +326,18 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, l
         layer_index = n_existing                         # preprocess_speech.py:41,67 (may be out of range -> per-file failure)
         log(f"Layer rule: hidden_states[{n_existing}] = hidden_states[number of files found in --save_path at start-up] "
             f"(the reference's rule, preprocess_speech.py:41,67; --use_n_layer selects hidden_states[--n_layer])")
+        if args.skip_existing:
+            # resuming under that rule writes the REST of the directory from another layer than the files already there
+            log("Error: --skip_existing resumes into a non-empty directory, where the reference's layer rule selects "
+                f"hidden_states[{n_existing}] instead of the layer the existing files hold; pass --use_n_layer --n_layer N "
+                "(or --use_average y) with --skip_existing")
+            log("Something went wrong, make sure everything is correct before running again!")
+            D.shutdown()
+            return 0
+        if n_existing > 0:
+            log(f"WARNING: --save_path already holds {n_existing} files, so this run writes hidden_states[{n_existing}] "
+                f"of {num_states} (index {num_states - 1} is the last layer); files already present are overwritten by "
+                "name, others stay -- a directory can end up holding mixed layers.  Use --use_n_layer --n_layer N to pick the layer.")
     else:
         # an out-of-range --n_layer is what ``hidden_states[N]`` raises per file in the reference (IndexError inside
         # the per-file try/except): keep the raw index and let every file report it, instead of crashing here

@@ -135,7 +135,7 @@ def test_driver_two_ranks_skip_existing_shards_before_filtering(tmp_path):
     sentinel = torch.zeros(1, 1)
     for i in (1, 4):
         torch.save(sentinel, os.path.join(root, "pt", f"utt_{i}.pt"))
-    mp.spawn(_driver_worker, args=(2, _free_port(), root, ["--skip_existing"]), nprocs=2, join=True)
+    mp.spawn(_driver_worker, args=(2, _free_port(), root, ["--skip_existing", "--use_n_layer", "--n_layer", "1"]), nprocs=2, join=True)
     got = [_extracted(root, r) for r in range(2)]
     want = [n for i, n in enumerate(LENGTHS) if i not in (1, 4)]
     assert sorted(got[0] + got[1]) == want, got

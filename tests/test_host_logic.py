@@ -452,6 +452,47 @@ def test_default_layer_rule_is_the_reference_rule(tmp_path, capsys):
     assert "Layer rule: hidden_states[1] (--n_layer)" in capsys.readouterr().out and float(torch.load(outw / "u0.pt")[0, 0]) == 1.0
 
 
+def test_layer_rule_and_resume_do_not_mix_layers_silently(tmp_path, capsys):
+    """The reference's rule (layer = files found at start-up) against this build's resume features: partial outputs a
+    killed run left (``*.pt.tmp``) are removed and not counted; a non-empty directory gets a WARNING naming the layer; and
+    --skip_existing -- which by construction resumes into a non-empty directory -- is refused unless the layer is chosen explicitly."""
+    class Stub:
+        pipelined = False
+
+        def __init__(self, args, whisper, device):
+            self.geo = C.with_layers(C.TINY_WAVLM, 6)
+            self.weight_source = "stub"
+
+        def extract(self, waves, layer_index):
+            return [torch.full((3, 4), float(layer_index)) for _ in waves]
+
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        write_wav(wav_dir / f"u{i}.wav", 0.1 * rng.standard_normal(4000))
+    out = tmp_path / "pt"
+    out.mkdir()
+    (out / "u0.pt.tmp").write_bytes(b"half a file")
+    (out / "u1.npy.tmp").write_bytes(b"half a file")
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out)], whisper=False, extractor_factory=Stub) == 0
+    log = capsys.readouterr().out
+    assert "It has 0 files in it" in log and "Layer rule: hidden_states[0]" in log and "WARNING" not in log
+    assert log.count("Removed stale partial output") == 2
+    assert sorted(os.listdir(out)) == ["u0.pt", "u1.pt", "u2.pt"] and float(torch.load(out / "u1.pt")[0, 0]) == 0.0
+    os.remove(out / "u2.pt")                                                # "a killed run": two of three outputs exist
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--skip_existing"], whisper=False, extractor_factory=Stub) == 0
+    log = capsys.readouterr().out
+    assert "Error: --skip_existing" in log and "hidden_states[2]" in log and not (out / "u2.pt").exists()
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--skip_existing", "--use_n_layer", "--n_layer", "0"],
+                       whisper=False, extractor_factory=Stub) == 0
+    capsys.readouterr()
+    assert [float(torch.load(out / f"u{i}.pt")[0, 0]) for i in range(3)] == [0.0, 0.0, 0.0]      # one layer in the directory
+    assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out)], whisper=False, extractor_factory=Stub) == 0
+    log = capsys.readouterr().out
+    assert "WARNING: --save_path already holds 3 files, so this run writes hidden_states[3]" in log
+
+
 def test_driver_on_an_empty_directory(tmp_path, capsys):
     """Nothing to do is not an error: the reference prints its header lines and exits 0 (preprocess_speech.py:87-124)."""
     class Stub:
