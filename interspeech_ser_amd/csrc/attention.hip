@@ -23,71 +23,14 @@
 //   * LDS images: K rows XOR-swizzled for conflict-free ds_read_b128 row reads, V 64-byte
 //     units XOR-swizzled so the 4 keys of a transposed read hit 4 different bank quarters.
 //   * FP32X mode: every product is the 3-term bf16 split (hi*hi + lo*hi + hi*lo).
-#include "ser_common.h"
+#include "attn_common.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <atomic>
 
-#define ABQ 128      // query rows per 4-wave block (an 8-wave block takes 256)
-#define ABKV 64      // keys per tile
-#define LOG2E 1.4426950408889634f
-
-struct AttnParams {
-    const unsigned short* qkv;
-    int64_t ld, plane;
-    int q_col, k_col, v_col;
-    const int32_t* frame_offs;
-    const int32_t* key_lens;   // optional [B]: keys >= key_lens[b] are padding (text encoders); queries keep all rows
-    const float* table;
-    int table_T;
-    const float* gate;
-    const float* gru_const;
-    int gate_col;
-    // gate pre-activations computed here from the layer input's operand copy (ser_attention_args.gate_x)
-    const unsigned short* gx;
-    int64_t gx_ld, gx_plane;
-    int gx_planes;
-    const float* gstat;        // [rows][2] relative mean, rstd (ser_gemm lnstat_out)
-    const unsigned short* gw;  // [planes][H][2][dh] folded weights in the operand format of `mode`
-    int64_t gw_plane;
-    const float* gcb;          // [H][4]
-    unsigned short* out;
-    int64_t ldo, out_plane;
-    int H, dh, B, nq;
-    int nitems;           // grid size of the one-block-per-item form (PERSIST blocks walk items up to it)
-    int bias_stride;      // floats per shifted bias copy in LDS
-    float scale;
-    // dense additive bias (DeBERTa's disentangled-attention terms, built by ser_deberta_bias): [B][H][T][b2d_ld] fp32 in the
-    // exp2 domain, zero where a pair is masked.  With it, padded QUERY rows (q >= key_lens[b]) follow HF's masked_fill(min) +
-    // softmax: every score equal -> the uniform average of all T value rows.
-    const float* bias2d;
-    int64_t b2d_ld;
-    int b2d_T;            // rows per (utterance, head) block of bias2d (= max_frames: uniform-length batches)
-#ifdef SER_ATTN_DBG
-    unsigned long long* dbg;   // phase timestamps of one wave (tools/attn_phases.py; never in the product build)
-#endif
-};
 #ifdef SER_ATTN_DBG
 extern "C" { void* ser_attn_dbg_ptr = nullptr; }
-#define DBG_P(i) do { __builtin_amdgcn_sched_barrier(0); dbg_p[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define DBG_T(i) do { __builtin_amdgcn_sched_barrier(0); if (dbg_on) dbg_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define DBG_T(i) do {} while (0)
-#define DBG_P(i) do {} while (0)
 #endif
-
-#ifdef SER_ATTN_DBG
-__constant__ int ser_attn_dbg_block_dev = 100;
-#endif
-template <int DHP>
-__device__ __forceinline__ int k_swz(int key, int chunk) {
-    return DHP == 64 ? (chunk ^ ((key >> 1) & 7)) : (chunk ^ (key & 15));
-}
-template <int DHP>
-__device__ __forceinline__ int v_unit_swz(int key, int unit) {
-    return DHP == 64 ? (unit ^ ((key >> 1) & 1)) : (unit ^ (key & 3));
-}
-
 // TBL: a relative-position bias table is present (WavLM) -- compile-time, so the plain path carries no bias code
 // and the bias path does not zero accumulators it is about to overwrite.
 // NWV waves (x 32 queries) per block.  8 waves halve the K/V global->LDS traffic and the bias-row copies per query:
@@ -102,11 +45,10 @@ __device__ __forceinline__ int v_unit_swz(int key, int unit) {
 // GB: the relative-position table is read from GLOBAL memory (L2: 2T-1 floats per head) instead of an LDS window -- the form for
 // utterances whose window (T + 192 distances x 4 shifted copies) does not fit the 160 KiB of LDS (beyond ~2 min of audio): the
 // reference has no length limit (preprocess_speech.py:47-50 runs whatever librosa.load returns).  Needs PRE and TBL, head dim <= 64.
-struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };       // 16-byte load from a 4-byte aligned address
-// PERSIST (round 3 experiment, SER_ATTN_PERSIST=1): the launch has only the blocks that are resident at once (two per CU) and each walks
-// (utterance, head, q-tile) items L, L + gridDim.x, ...
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false, bool PERSIST = false>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : ((DHP == 128 && mode_traits<MODE>::planes == 2) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2)))
+// (Round 3's persistent form -- resident blocks walking the items -- and its 8-wave form measured +- 0 / -1.2 % on the step and were
+// removed from the build in round 4: DESIGN.md section 10 keeps the record.)
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
+__global__ __launch_bounds__(64 * NWV, (DHP == 128 && mode_traits<MODE>::planes == 2) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
     // NP: planes of Q and K (the logit path S = K Q^T: 3 products when 2), NPV: planes of V and P.  FP16Q (the "f16q" numerics
@@ -137,16 +79,14 @@ void attention_kernel(const AttnParams p) {
     // XCD-aware decode of the linear block id L: the q-tiles of one (utterance, head) sit at
     // L, L+8, L+16, ... -> same XCD (blocks are dealt round-robin over the 8 XCDs), close in time,
     // so K/V are fetched from HBM once and re-read from that XCD's L2 by the other q-tiles.
-    int L = blockIdx.x;
-    do {
-    if (PERSIST && L != (int)blockIdx.x) __syncthreads();          // every wave has left the previous item's LDS tiles / bias window
+    const int L = blockIdx.x;
     const int bh = (L / (8 * p.nq)) * 8 + (L & 7), qt = (L >> 3) % p.nq;
-    if (bh >= p.H * p.B) continue;
+    if (bh >= p.H * p.B) return;
     const int h = bh % p.H, b = bh / p.H;
     const int row0 = p.frame_offs[b];
     const int T = p.frame_offs[b + 1] - row0;
     const int q0 = qt * (32 * NWV);
-    if (q0 >= T) continue;
+    if (q0 >= T) return;
     DBG_P(0);
     const int dh = p.dh;
     const int hh = lane >> 5, l31 = lane & 31;
@@ -564,7 +504,8 @@ void attention_kernel(const AttnParams p) {
 
         // ---- P = exp2(S - m) and O^T += V^T P^T, 16 keys at a time: accumulator registers 8s..8s+7 of a key half
         // are the B fragment of k-step s, so the exponentials of the next 16 keys issue while these MFMAs run
-        f32x2 lsum2 = {0.f, 0.f};                                    // LAZY: the row sum through v_pk_add_f32 (two scores per VALU issue)
+        f32x2 lsum2 = {0.f, 0.f};                                    // LAZY: the row sum through v_pk_add_f32 (two scores per VALU issue; round 4: plain adds
+                                                                     // under -fno-slp-vectorize measured no different, profiles/r04_attn_experiments.txt)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -669,12 +610,11 @@ void attention_kernel(const AttnParams p) {
                                      ot[ds][4 * r4 + 2] * inv, ot[ds][4 * r4 + 3] * inv);
             }
     }
-    } while (PERSIST && (L += gridDim.x) < p.nitems);
 }
 
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false, bool PERSIST = false>
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D, GB, PERSIST>;
+    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D, GB>;
     static std::atomic<bool> ready{false};          // several host threads launch (see gemm.hip launch_mode)
     if (lds > 65536 && !ready.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -733,10 +673,7 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     const int dhp = dh <= 64 ? 64 : 128;
     const int np = (mode == SER_MODE_FP32X || mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q) ? 2 : 1;      // planes of q / k
     const int npv = (mode == SER_MODE_FP32X || mode == SER_MODE_FP16X) ? 2 : 1;                                 // planes of v
-    // 8-wave blocks: -1.1 us per launch in isolation (24.4 -> 23.3 us at 8 x 499 frames), +1.2 % on the real step
-    // (512-thread blocks leave no room for the other utterance group's blocks on the CU): off unless SER_ATTN_W8=1
-    static const int w8_knob = [] { const char* e = getenv("SER_ATTN_W8"); return e ? atoi(e) : 0; }();
-    const int nwv = (w8_knob && mode == SER_MODE_BF16 && dhp == 64 && max_frames > ABQ) ? 8 : 4;
+    const int nwv = 4;
     const int nch = ABKV * (dhp / 8) / (64 * nwv);
     const int nbuf = (nch * (np + npv) <= 8) ? 2 : 1;
     // copy stride == 16 (mod 64) floats: the 4 shifted copies x the 4 query phases of a ds_read_b128
@@ -771,13 +708,12 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     p.nitems = (int)grid.x;
     hipStream_t s = (hipStream_t)stream;
     const bool pre = scale <= 0.f;
-    {   // SER_ATTN_PERSIST=1 (A/B knob, default 0; the bf16 WavLM form only): 512 resident blocks walk the items
-        static const int persist = [] { const char* e = getenv("SER_ATTN_PERSIST"); return e ? atoi(e) : 0; }();
-        if (persist && pre && table && !gbias && !bias2d && mode == SER_MODE_BF16 && dhp == 64 && nwv == 4 && grid.x > 512u) {
-            grid.x = 512u;
-            return launch_attention<64, SER_MODE_BF16, true, true, 4, false, false, true>(p, grid, lds, s);
-        }
+#ifdef SER_EXPERIMENTS
+    if (!gbias) {                                                 // round-4 experiment (make EXPERIMENTS=1; SER_ATTN_RESIDENT=1): K / V of a whole
+        const int r = ser_attention_resident(p, mode, max_frames, s);      // (utterance, head) resident in LDS, attention_res.hip -- not faster, see its header
+        if (r <= 0) return r;
     }
+#endif
 #define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
                               : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
     if (gbias) {
@@ -792,9 +728,6 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     if (bias2d)
         return mode == SER_MODE_FP32X ? launch_attention<64, SER_MODE_FP32X, true, false, 4, true>(p, grid, lds, s)
                                       : launch_attention<64, SER_MODE_BF16, true, false, 4, true>(p, grid, lds, s);
-    if (dhp == 64 && mode == SER_MODE_BF16 && nwv == 8)
-        return pre ? (table ? launch_attention<64, SER_MODE_BF16, true, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, true, false, 8>(p, grid, lds, s))
-                   : (table ? launch_attention<64, SER_MODE_BF16, false, true, 8>(p, grid, lds, s) : launch_attention<64, SER_MODE_BF16, false, false, 8>(p, grid, lds, s));
     if (mode == SER_MODE_FP16) return dhp == 64 ? SER_ATTN(64, SER_MODE_FP16) : SER_ATTN(128, SER_MODE_FP16);
     if (mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q) {      // "f16a" / "f16q": the host always pre-scales q; only the PRE forms are built
         if (!pre) return ser_fail(-13, "ser_attention: FP16X / FP16Q need a pre-scaled q (scale <= 0)");

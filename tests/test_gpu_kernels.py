@@ -709,9 +709,10 @@ def test_attention_fused_gate_columns(L, mode):
     assert err < mode_tol(mode, 3e-2, 1e-4), err
 
 
+@pytest.mark.parametrize("pre", [False, True])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("dh,H", [(64, 2), (64, 16), (32, 3)])
-def test_attention_gate_from_operand_copy(L, mode, dh, H):
+def test_attention_gate_from_operand_copy(L, mode, dh, H, pre):
     """ser_attention_v with gate_x: the WavLM gate's two pre-activations per (row, head) are computed INSIDE the kernel from the layer
     input's operand copy, (relative mean, rstd) per row and the LayerNorm-folded weights (HF modeling_wavlm.py:167-180 on
     LayerNorm1(x)) -- against an fp64 statement of LayerNorm -> Linear(dh, 8) -> sums of four -> sigmoids."""
@@ -720,8 +721,12 @@ def test_attention_gate_from_operand_copy(L, mode, dh, H):
     g = torch.Generator().manual_seed(dh + H)
     qkv = torch.randn(M, 3 * D, generator=g)
     qkv[:, : 2 * D] *= 1.5
+    if pre:                                            # what the encoders launch: q pre-scaled by the projection epilogue (head dim 64, single-plane
+        qkv[:, :D] *= dh ** -0.5 * 1.4426950408889634  # modes, <= 512 frames: the resident-K/V form, csrc/attention_res.hip)
     qa = to_act(qkv, mode)
     qv = act_value(qa).cpu().double()
+    if pre:
+        qv[:, :D] /= dh ** -0.5 * 1.4426950408889634
     x = torch.randn(M, D, generator=g) * 2.0 + torch.randn(M, 1, generator=g)          # layer input; rows with their own offsets
     xa = to_act(x, mode)
     xv = act_value(xa).cpu().double()                                                   # what the kernel reads
@@ -758,7 +763,7 @@ def test_attention_gate_from_operand_copy(L, mode, dh, H):
     a_ = L.AttentionArgs()
     a_.qkv, a_.ld, a_.plane_stride, a_.q_col, a_.k_col, a_.v_col, a_.B = qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, len(Ts)
     a_.frame_offs, a_.table, a_.max_frames, a_.table_T = foffs.data_ptr(), td.data_ptr(), Tmax, Tmax
-    a_.out, a_.ldo, a_.out_plane_stride, a_.H, a_.dh, a_.scale, a_.mode = out.data_ptr(), D, M * D, H, dh, dh ** -0.5, mode
+    a_.out, a_.ldo, a_.out_plane_stride, a_.H, a_.dh, a_.scale, a_.mode = out.data_ptr(), D, M * D, H, dh, (-1.0 if pre else dh ** -0.5), mode
     a_.gru_const = cd.data_ptr()
     a_.gate_x, a_.gate_x_ld, a_.gate_x_plane_stride, a_.gate_x_planes = xa.data_ptr(), D, M * D, planes
     a_.gate_stat, a_.gate_w, a_.gate_cb, a_.gate_w_plane_stride = std.data_ptr(), gwa.data_ptr(), cbd.data_ptr(), 2 * H * dh
@@ -864,6 +869,56 @@ def test_attention_stale_running_maximum(L, mode, dh, bias):
     (almost) all padding.  (fp32x bound: one-hot rows over |v| ~ 4 with logits of +-100 -- 1.5e-4 on either form.)"""
     err = _prescaled_case(L, mode, dh, bias, [700, 65, 1, 130], ramp=100.0)
     assert err < mode_tol(mode, 3e-2, 3e-4), err
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("bias", [True, False])
+@pytest.mark.parametrize("Ts", [[499, 1, 31, 33, 64, 65, 128, 257, 512], [500, 499, 448, 449, 3], [150]])
+def test_attention_resident_form(L, mode, bias, Ts):
+    """csrc/attention_res.hip: head dim 64, single-plane mode, pre-scaled q, <= 512 frames -> K and V of a whole (utterance, head) stay
+    in LDS (LDS-DMA with a counted wait per tile for the first query block of a wave, no synchronisation for the later ones).  Ragged
+    batches whose lengths sit on every tile / query-block edge (1, 31 | 33, 64 | 65, 448 | 449, 512), a climbing score ramp with a late
+    spike so that the stale running maximum is raised in later tiles, with and without the WavLM bias table; H = 2 makes the launch
+    split every (utterance, head) over two blocks (fewer than 128 pairs), the gate_x form and H = 16 are
+    test_attention_gate_from_operand_copy[pre]."""
+    err = _prescaled_case(L, mode, 64, bias, Ts, ramp=60.0)
+    assert err < mode_tol(mode, 3e-2, 3e-4), err
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_attention_resident_form_full_batch(L, mode):
+    """The launch shape of BASELINE configs[1]: 16 utterances x 16 heads = 256 (utterance, head) pairs, one block each, ragged lengths up to
+    499 frames, WavLM bias + gate[]."""
+    H, dh = 16, 64
+    Ts = [499, 499, 149, 333, 250, 499, 64, 401, 499, 200, 450, 499, 97, 499, 310, 499]
+    D, M, Tmax = H * dh, sum(Ts), 499
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    qkv[:, : 2 * D] *= 1.5
+    qkv[:, :D] *= dh ** -0.5 * 1.4426950408889634
+    qa = to_act(qkv, mode)
+    qv = act_value(qa).cpu().double()
+    qv[:, :D] /= dh ** -0.5 * 1.4426950408889634
+    table = torch.randn(H, 2 * Tmax - 1, generator=g)
+    gate = torch.rand(M, H, generator=g) * 2
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    out = torch.zeros(1, M, D, dtype=act_dtype(mode), device=DEV)
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    td, gd = table.to(DEV), gate.to(DEV)
+    L.check(L.lib.ser_attention(qa.data_ptr(), 3 * D, M * 3 * D, 0, D, 2 * D, foffs.data_ptr(), len(Ts), Tmax, td.data_ptr(), Tmax,
+                                gd.data_ptr(), out.data_ptr(), D, M * D, H, dh, -1.0, mode, 0, None, None, None, 0, stream()))
+    torch.cuda.synchronize()
+    got = act_value(out).cpu().double()
+    worst = 0.0
+    for b in (0, 2, 6, 12, 15):                                 # full-length, short and one-tile utterances; every head
+        T = Ts[b]
+        blk = qv[offs[b]:offs[b + 1]]
+        q, k, v = (blk[:, i * D:(i + 1) * D].view(T, H, dh).permute(1, 0, 2) for i in range(3))
+        c = Tmax - 1
+        o = attention_reference(q, k, v, dh ** -0.5, table[:, c - (T - 1): c + T].double(), gate[offs[b]:offs[b + 1]].double())
+        worst = max(worst, (got[offs[b]:offs[b + 1]] - o.permute(1, 0, 2).reshape(T, D)).abs().max().item())
+    assert bool(torch.isfinite(got).all())
+    assert worst < mode_tol(mode, 3e-2, 3e-4), worst
 
 
 def test_gemm_column_scale(L):
