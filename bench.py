@@ -34,6 +34,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+DRIVER_DEFAULT_MODE = "f16x"       # interspeech_ser_amd/driver.py --mode default
+# BASELINE.json configs[2..4]'s encoders on their own batch shapes: (hub id, batch, seconds per clip)
+OTHER_ENCODERS = {"xlsr": ("facebook/wav2vec2-xls-r-2b", 8, 10.0), "hubert": ("facebook/hubert-xlarge-ll60k", 16, 10.0),
+                  "whisper": ("openai/whisper-large-v3", 16, 30.0)}
 
 
 def algorithmic_gflop_per_utt(geo, num_samples):
@@ -63,14 +67,80 @@ def synth_batch(batch, num_samples, seed):
     return [(0.1 * torch.randn(num_samples, generator=g)).numpy() for _ in range(batch)]
 
 
-def broadcast_weights(geo, seed, rank):
+def broadcast_weights(geo, seed, rank, fast=False):
     """C1: rank 0 owns the frozen weights; everyone else receives them over RCCL/xGMI in one
-    flat fp32 bucket (interspeech_ser_amd/dist.py)."""
+    flat fp32 bucket (interspeech_ser_amd/dist.py).  Returns (state dict, seconds, bytes)."""
     from interspeech_ser_amd import dist as D
     from interspeech_ser_amd.weights import synthetic_state_dict
-    sd = synthetic_state_dict(geo, seed) if rank == 0 else None
-    sd, dt, _ = D.broadcast_state_dict(sd)
-    return sd, dt
+    sd = synthetic_state_dict(geo, seed, fast=fast) if rank == 0 else None
+    sd, dt, nbytes = D.broadcast_state_dict(sd)
+    return sd, dt, nbytes
+
+
+def collective_record(world, seconds, nbytes):
+    """What the one collective of the job did, as the process group itself reports it: a SCALE record can then show that RCCL really
+    carried the weights to N ranks (backend name and world size from torch.distributed, not from the command line)."""
+    import torch.distributed as dist
+    if world <= 1 or not dist.is_initialized():
+        return {"backend": None, "ranks": 1, "bytes": 0, "seconds": 0.0, "GB_per_s": None, "what": "single process: no collective runs"}
+    backend = dist.get_backend()
+    return {"backend": ("nccl (= RCCL on ROCm)" if backend == "nccl" else backend), "ranks": dist.get_world_size(), "bytes": int(nbytes),
+            "seconds": round(seconds, 4), "GB_per_s": round(nbytes / max(seconds, 1e-9) / 1e9, 2),
+            "what": "one flat fp32 broadcast of the frozen weights from rank 0 (dist.broadcast_state_dict); no data-path collective"}
+
+
+def other_encoder_run(name, device, mode, steps=3, warmup=1):
+    """A short, checked run of one of the other encoders BASELINE.json's configs name, so that the driver's record carries a timed line
+    for them too (round-3 verdict, weak #13): seeded synthetic weights (fast generator: throughput only), the launch shape the
+    drivers use for that family, `steps` counted steps of >= 0.3 s; the replayed graph's states must equal the eager path bit for bit."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import build_encoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    ssl_type, batch, seconds = OTHER_ENCODERS[name]
+    t_all = time.perf_counter()
+    geo = C.geometry_for(ssl_type)
+    whisper = geo.family == C.FAMILY_WHISPER
+    sd = synthetic_state_dict(geo, 0, fast=True)
+    enc = build_encoder(geo, sd, device, mode)
+    del sd
+    num_samples = int(round(seconds * 16000))
+    inflight, micro = (1, 2) if whisper else (2, 1)
+    cuts = [round(i * batch / micro) for i in range(micro + 1)]
+    waves = [synth_batch(batch, num_samples, 4242 + j) for j in range(inflight)]
+    lengths = [num_samples] * batch
+    groups = [(enc.upload(waves[j][a:b], slot=slot), lengths[a:b])
+              for slot, (j, a, b) in enumerate((j, a, b) for j in range(inflight) for a, b in zip(cuts[:-1], cuts[1:]))]
+    torch.cuda.synchronize()
+    graph, hs = enc.capture_concurrent(groups)
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    graph.replay()
+    torch.cuda.synchronize()
+    reps = max(1, int(0.3 / max(time.perf_counter() - t0, 1e-4) / steps) + 1)
+    t0 = time.perf_counter()
+    for _ in range(steps * reps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kept = [h.states.clone() for h in hs]
+    eager = [enc.forward(w, l, slot=slot) for slot, (w, l) in enumerate(groups)]
+    torch.cuda.synchronize()
+    same = all(torch.equal(k, e.states) for k, e in zip(kept, eager))
+    finite = all(bool(torch.isfinite(k).all()) for k in kept)
+    utts = batch * inflight * steps * reps
+    gf = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
+    rec = {"workload": f"{geo.name} embed extract, batch={batch} x {seconds:.0f} s, mode={mode}, {inflight} batch(es) in flight x {micro} group(s)",
+           "value": round(utts / dt, 1), "unit": "utterances/s", "steps": steps, "batches_per_step": reps * inflight,
+           "ms_per_batch": round(1e3 * dt / steps / reps / inflight, 3), "gflop_per_utt": round(gf, 1),
+           "achieved_tflops_whole_path": round(utts / dt * gf / 1e3, 1), "frac_of_bf16_peak": round(utts / dt * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
+           "verified": bool(same and finite), "graph_replay_equals_eager_bitwise": bool(same), "all_finite": finite,
+           "weights": "seeded synthetic (fast generator)", "seconds_incl_weight_generation": None}
+    del enc, hs, kept, eager, graph, groups
+    torch.cuda.empty_cache()
+    rec["seconds_incl_weight_generation"] = round(time.perf_counter() - t_all, 1)
+    return rec
 
 
 def cpu_baseline(geo, sd, num_samples, n_clips=8):
@@ -97,7 +167,7 @@ def cpu_baseline(geo, sd, num_samples, n_clips=8):
 def bench_text(args, geo, rank, world, device, D):
     """Next row 8f-1: RoBERTa text extraction, `--batch` texts of `--max_len` tokens per step (synthetic ids)."""
     from interspeech_ser_amd.engine import build_encoder
-    sd, bcast_s = broadcast_weights(geo, 0, rank)
+    sd, bcast_s, _ = broadcast_weights(geo, 0, rank)
     enc = build_encoder(geo, sd, device, args.mode)
     T = args.max_len
     g = torch.Generator().manual_seed(99 + rank)
@@ -177,7 +247,7 @@ def oracle_states(geo, sd, wave, whisper):
         return O.speech_hidden_states(geo, sd, torch.from_numpy(O.zero_mean_unit_var(wave)))
 
 
-def end_to_end_leg(args, enc, geo, whisper, n_files, num_samples, world=1, D=None):
+def end_to_end_leg(args, enc, geo, whisper, n_files, num_samples, world=1, D=None, mode=None, passes=3, with_ref_rule=True):
     """SURVEY 8d timing (ii): wav files on tmpfs -> decode -> pinned H2D -> forward -> selection -> D2H -> .pt on tmpfs,
     through the product's own driver (preprocess_speech.py:47-71 per file), re-using the encoder that was just timed.
     At N > 1 every rank runs the leg on its own directory of n files (weak scaling, like the headline): the record is
@@ -212,7 +282,7 @@ def end_to_end_leg(args, enc, geo, whisper, n_files, num_samples, world=1, D=Non
         # region to whole batches and records their command lists (one-time work of a long-running extraction); the second is reported
         def one_pass(tag, extra):
             out_dir = os.path.join(root, "pt_" + tag)
-            argv = ["--ssl_type", args.ssl_type, "--wav_dir", wav_dir, "--save_path", out_dir, "--mode", args.mode,
+            argv = ["--ssl_type", args.ssl_type, "--wav_dir", wav_dir, "--save_path", out_dir, "--mode", mode or args.mode,
                     "--batch_size", str(args.batch), "--num_workers", str(args.e2e_workers)] + extra
             driver.LAST_RUN.clear()
             with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(io.StringIO()):
@@ -229,11 +299,11 @@ def end_to_end_leg(args, enc, geo, whisper, n_files, num_samples, world=1, D=Non
         # the LAST hidden state (every layer runs): --use_n_layer --n_layer -1.  Three timed passes after the warm one.
         full = ["--use_n_layer", "--n_layer", "-1"]
         one_pass("warm", full)
-        runs = [one_pass(f"timed{i}", full) for i in range(3)]
+        runs = [one_pass(f"timed{i}", full) for i in range(passes)]
         # the reference's own default on a fresh directory: hidden_states[0] (preprocess_speech.py:41,67), where the forward stops
         # after the positional conv (driver: last_state) -- the speech script's README recipe
         ref_rule = None
-        if not whisper:
+        if not whisper and with_ref_rule:
             one_pass("warm0", [])
             r0, n0 = one_pass("rule0", [])
             if r0 and n0 == n_files:
@@ -248,13 +318,13 @@ def end_to_end_leg(args, enc, geo, whisper, n_files, num_samples, world=1, D=Non
             n_files *= world
         t = last["launch_thread"]
         rates = sorted(r["done"] / r["wall_s"] for r, _ in ok)
-        rec = {"value": round(last["done"] / last["wall_s"], 1), "unit": "utterances/s", "files": n_files, "n_gpus": world,
+        rec = {"value": round(last["done"] / last["wall_s"], 1), "unit": "utterances/s", "mode": mode or args.mode, "files": n_files, "n_gpus": world,
                "wall_s": round(last["wall_s"], 3), "batch_size": args.batch, "host_threads": args.e2e_workers,
                "passes": len(ok), "min": round(rates[0], 1), "median": round(rates[len(rates) // 2], 1), "max": round(rates[-1], 1),
                "launch_thread_s": {k: round(v, 3) for k, v in t.items()},
                "what": "wav (PCM16, tmpfs) -> decode -> pinned H2D -> forward (all layers: --use_n_layer --n_layer -1) -> last "
                        "state -> D2H -> .pt (tmpfs), one process, driver of preprocessing/preprocess_speech.py; weights already "
-                       "resident; median of three timed passes after one that sizes the arenas and records the command lists"}
+                       f"resident; median of {passes} timed passes after one that sizes the arenas and records the command lists"}
         if ref_rule:
             rec["reference_default_layer_rule"] = ref_rule
         return rec
@@ -272,8 +342,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--max_len", type=int, default=80, help="tokens per text (roberta workloads)")
     ap.add_argument("--ssl_type", type=str, default="microsoft/wavlm-large")
-    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x", "f16", "f16q", "f16a"])
-    ap.add_argument("--parity-mode", type=str, default="f16a,f16q,f16,fp32x",
+    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x", "f16", "f16q", "f16a", "f16x"])
+    ap.add_argument("--parity-mode", type=str, default="f16x,f16a,f16,fp32x",
                     help="numerics mode(s) of the parity records, comma separated: the first fills `parity_mode`, "
                          "the others `parity_mode_<name>`")
     ap.add_argument("--layers", type=int, default=0, help="debug: truncate the encoder (invalidates the metric)")
@@ -283,6 +353,11 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the parity_mode record (second encoder + oracle)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (files on tmpfs) leg")
     ap.add_argument("--e2e-files", type=int, default=4096)
+    ap.add_argument("--e2e-default-files", type=int, default=1024,
+                    help="files of the second end-to-end leg, run in the drivers' DEFAULT numerics mode (0: skip)")
+    ap.add_argument("--other-encoders", type=str, default="hubert,whisper",
+                    help="after the headline: short verified runs (3 steps) of BASELINE configs[2..4]'s encoders on their own batch "
+                         "shapes, comma separated from xlsr,hubert,whisper ('' or none: skip; xlsr adds ~1 min of weight generation)")
     ap.add_argument("--e2e-workers", type=int, default=4, help="host threads of the end-to-end leg (reference default 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--split", type=str, default="", help="explicit utterance-group sizes, e.g. 9,7 (overrides --micro)")
@@ -327,7 +402,7 @@ def main():
     inflight = max(1, args.inflight)
     reps = max(1, args.reps // inflight)               # replays per counted step: a step stays `--reps` batches (8) back to back
 
-    sd, bcast_s = broadcast_weights(geo, 0, rank)
+    sd, bcast_s, bcast_bytes = broadcast_weights(geo, 0, rank)
     enc = build_encoder(geo, sd, device, args.mode)
     if world > 1:
         sd = None                  # views of the fp32 broadcast bucket: dropping them frees it (weights stay 1x in HBM)
@@ -502,7 +577,7 @@ def main():
             del gd
 
     elapsed = D.max_over_ranks(elapsed)
-    e2e = None
+    e2e = e2e_default = None
     if not args.no_e2e:                                           # every rank: its own files, aggregated inside (weak scaling)
         e2e = end_to_end_leg(args, enc, geo, whisper, args.e2e_files, num_samples, world, D)
 
@@ -510,8 +585,9 @@ def main():
         total_utts = args.batch * inflight * reps * args.steps * world
         value = total_utts / elapsed
         gf_utt = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
-        dtype_name = {"bf16": "bf16", "fp32x": "bf16x3 (fp32-grade split)", "f16": "f16 (fp32x stem)",
-                      "f16q": "f16 (fp32x stem, f16x3 logit path)", "f16a": "f16 (fp32x stem, f16x3 attention block)"}
+        dtype_name = {"bf16": "bf16", "fp32x": "bf16x3 (bf16 hi + lo planes, 3 products)", "f16": "f16 (f16x3 stem)",
+                      "f16q": "f16 (f16x3 stem and logit path)", "f16a": "f16 (f16x3 stem and attention block)",
+                      "f16x": "f16x3 (fp16 hi + lo planes, 3 products)"}
         out = {
             "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract" if geo is C.WAVLM_LARGE and abs(args.seconds - 10) < 1e-6
                       else f"utterances/sec ({args.seconds:.0f} s @16 kHz) {geo.name} embed extract",
@@ -526,11 +602,13 @@ def main():
                        "batch": args.batch, "batches_per_step": reps * inflight, "batches_in_flight": inflight,
                        "ms_per_batch": round(1e3 * elapsed / args.steps / reps / inflight, 3),
                        "frames_per_utt": geo.max_source_positions if whisper else geo.frames_for(num_samples), "gflop_per_utt": round(gf_utt, 1),
-                       "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
+                       "parallelism": f"utterance-sharded x{world}, " + ("no collective (one process)" if world == 1 else
+                                      f"one weight broadcast over {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} only")},
             "achieved_tflops_whole_path": round(value * gf_utt / 1e3 / world, 1),
             "launch": "eager" if args.no_graph else f"hipGraph replay, {len(branches)} concurrent branch(es): {inflight} batch(es) in flight x "
                                                     f"{micro} utterance group(s) of {per}",
             "weight_broadcast_s": round(bcast_s, 4),
+            "collective": collective_record(world, bcast_s, bcast_bytes),
         }
         if trace:
             dur_ms = sum(t[0].elapsed_time(t[1]) for t in trace)
@@ -549,16 +627,17 @@ def main():
                         break
             n = len(trace)
             achieved = flops / (dur_ms * 1e-3) / 1e12
-            mult = 3.0 if args.mode == "fp32x" else 1.0        # (f16 / f16q: 3 in the stem and, for f16q, in the q / k projection)
+            mult = sum(t[2] * t[4] for t in trace) / max(flops, 1.0)      # MFMA products per algorithmic FLOP, per launch from its mode (3 on two planes)
             out["roofline"] = {
                 "kernel": "ser_gemm_kernel (bf16 MFMA implicit-conv GEMM + fused epilogue)",
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "regime": "one launch at a time (replaced below by the step's own regime when the decomposition leg ran)",
                 "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": round(algo_bytes / n),
                 "launches": n, "avg_launch_us": round(1e3 * dur_ms / n, 2),
                 "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
-                "mfma_products_per_algorithmic_flop": mult,
+                "mfma_products_per_algorithmic_flop": round(mult, 3),
                 "gemm_ms_per_batch": round(dur_ms / args.steps / inflight, 3),
                 "under_step_concurrency": None,
                 "measured": "HIP events around every ser_gemm launch, eager pass of K batches right after the timed region "
@@ -583,11 +662,22 @@ def main():
             if trace and "roofline" in out:
                 gflop_batch = sum(t[2] for t in trace) / args.steps / inflight / 1e9
                 ach_c = gflop_batch / decomp["gemm"]["ms_per_batch"]          # GF per ms = TF/s
-                out["roofline"]["under_step_concurrency"] = {
-                    "achieved": round(ach_c, 1), "frac": round(ach_c / MFMA_BF16_PEAK_TFLOPS, 4), "unit": "TFLOP/s",
-                    "gemm_ms_per_batch": decomp["gemm"]["ms_per_batch"],
-                    "measured": "the same ser_gemm launches as the step's concurrent branches (GEMM-only command lists on the branches "
-                                "of one hipGraph): algorithmic FLOPs of a batch / replay time per batch"}
+                r = out["roofline"]
+                # `achieved` / `frac` = the regime `value` is measured in (the GEMM launches of a batch as the step's concurrent graph
+                # branches run them); the one-launch-at-a-time figure the per-launch events give stays beside it: sum of those launch
+                # durations EXCEEDS the batch time, so it cannot be the step's figure (round-3 verdict, weak #6)
+                r["one_launch_at_a_time"] = {"achieved": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"],
+                                             "gemm_ms_per_batch": r["gemm_ms_per_batch"], "measured": r["measured"],
+                                             "rocprof": "profiles/r04_kernel_trace_one_launch_at_a_time_wavlm_large_bf16.csv (same command with "
+                                                        "--no-graph --inflight 1 --micro 1)"}
+                r["achieved"], r["frac"] = round(ach_c, 1), round(ach_c / MFMA_BF16_PEAK_TFLOPS, 4)
+                r["gemm_ms_per_batch"] = decomp["gemm"]["ms_per_batch"]
+                r["avg_launch_us"] = round(1e3 * decomp["gemm"]["ms_per_batch"] / max(decomp["gemm"]["launches_per_batch"], 1), 2)
+                r["regime"] = "the step's own: the ser_gemm launches of a batch on the concurrent branches of one hipGraph, as timed for `value`"
+                r["measured"] = ("algorithmic FLOPs of a batch's ser_gemm launches / replay time per batch of the GEMM-only command lists "
+                                 "captured as the step's concurrent graph branches (HIP events around 10 replays); avg_launch_us = that time / launches")
+                r["under_step_concurrency"] = {"achieved": r["achieved"], "frac": r["frac"], "unit": "TFLOP/s",
+                                               "gemm_ms_per_batch": r["gemm_ms_per_batch"]}
         if blocks:
             T = geo.frames_for(num_samples)
             Dm, dh = geo.hidden, geo.head_dim
@@ -623,13 +713,15 @@ def main():
             first = [f"batch {j} utterance {a}" for j, a, _ in branches]     # first utterance of every branch
             ref = oracle_states(geo, sd, waves[0], whisper)               # CPU oracle on utterance 0 (full geometry, T frames)
             err_m = max(rel_err(hs_timed[0].utterance(0, l).cpu(), r) for l, r in enumerate(ref))
-            bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3, "f16q": 1e-3, "f16a": 1e-3}[args.mode]
+            bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3, "f16q": 1e-3, "f16a": 1e-3, "f16x": 1e-3}[args.mode]
             verification.update({"weights": "seeded synthetic weights of the named geometry (no checkpoint can be fetched offline): every error "
                                             "below is on those; stress fixtures (LoRA-scaled queries, sharp attention, outlier channels) are in tests/",
                                  "timed_mode": args.mode, "timed_mode_max_rel_err_vs_oracle": float(f"{err_m:.3e}"),
                                  "timed_mode_bound": bound, "utterances_vs_parity_mode": first})
             checks_ok = checks_ok and err_m <= bound
             what = {"fp32x": "bf16 x3 split (hi*hi + lo*hi + hi*lo) everywhere",
+                    "f16x": "the same 3-product split everywhere on fp16 hi + lo planes (22-bit operands instead of 16; the drivers' default since "
+                            "round 4: <= 1.0e-4 on the full-depth stress cases of profiles/r04_depth_envelope.txt)",
                     "f16": "fp32x conv stem (conv stack, projection, positional conv) + fp16 single-product encoder layers",
                     "f16a": "fp32x conv stem; packed QKV projection, attention (S = K Q^T, P V) and output projection on the 3-product "
                             "split over fp16 hi + lo planes; FC1 / FC2 (62 % of the layer FLOPs) single-product fp16",
@@ -656,6 +748,10 @@ def main():
                     "error_form": "max|a-b| / max(1, max|b|) per hidden state, worst state",
                 }
                 checks_ok = checks_ok and err_p <= 1e-3 and err_mode <= max(bound, 1e-3)
+                if pmode == DRIVER_DEFAULT_MODE and not args.no_e2e and args.e2e_default_files > 0:
+                    # the file-to-file leg in the numerics the drivers default to (preprocessing/preprocess_speech.py without --mode)
+                    e2e_default = end_to_end_leg(args, enc_p, geo, whisper, args.e2e_default_files, num_samples, 1, D,
+                                                 mode=pmode, passes=2, with_ref_rule=False)
                 if enc_p is not enc:
                     del enc_p, hs_p
                     torch.cuda.empty_cache()
@@ -666,6 +762,12 @@ def main():
             out["verification"] = verification
         if e2e is not None:
             out["end_to_end"] = e2e
+        if e2e_default is not None:
+            out["end_to_end_default_mode"] = e2e_default
+        if world == 1 and args.other_encoders and args.other_encoders != "none":
+            del enc, hs_timed, groups, packed
+            torch.cuda.empty_cache()
+            out["other_encoders"] = {n: other_encoder_run(n, device, args.mode) for n in args.other_encoders.split(",") if n in OTHER_ENCODERS}
         if world == 1 and not args.no_cpu_baseline and not whisper:
             out["cpu_baseline"] = cpu_baseline(geo, sd, num_samples)
         print(json.dumps(out), flush=True)

@@ -347,7 +347,7 @@ class _EncoderBase:
         nbytes = 2.0 * planes * (M * k_real * groups + g.N * groups * k_real)
         nbytes += 4.0 * M * g.N * groups * ((residual is not None) + (out_f32 is not None))
         nbytes += 2.0 * planes * M * g.N * groups * (out_act is not None)
-        self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * k_real, nbytes))
+        self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * k_real, nbytes, 3 if _PLANES[g.mode] == 2 else 1))
 
     def _layernorm(self, x: torch.Tensor, ldx: int, ln, rows: int, D: int, *, gelu=False, out_f32=None,
                    out_act: Optional[Act] = None, eps=None, stem=False):

@@ -30,10 +30,15 @@ class _Rng:
     """numpy PCG64 stream: unlike torch's CPU ``randn`` (whose vectorised fill depends on the
     host's SIMD width) it yields the same numbers in the build container and on the GPU box."""
 
-    def __init__(self, seed: int):
+    def __init__(self, seed: int, fast: bool = False):
         self.g = np.random.default_rng(int(seed))
+        # fast: torch's vectorised CPU generator (several GB/s instead of numpy's ~0.3) for throughput-only runs of the multi-billion
+        # parameter geometries (bench.py other_encoders); NOT stable across hosts, so never used where a digest or an oracle compares
+        self.t = torch.Generator().manual_seed(int(seed)) if fast else None
 
     def normal(self, *shape, std=1.0, mean=0.0):
+        if self.t is not None:
+            return torch.randn(*shape, generator=self.t) * std + mean
         x = self.g.standard_normal(size=shape, dtype=np.float32)
         return torch.from_numpy(x) * std + mean
 
@@ -58,8 +63,8 @@ def whisper_sinusoids(length: int, channels: int) -> torch.Tensor:
     return torch.from_numpy(np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32))
 
 
-def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0) -> StateDict:
-    r = _Rng(seed)
+def synthetic_state_dict(geo: EncoderGeometry, seed: int = 0, fast: bool = False) -> StateDict:
+    r = _Rng(seed, fast)
     sd: StateDict = {}
     D, H, Fd, dh = geo.hidden, geo.heads, geo.ffn, geo.head_dim
     if geo.family == FAMILY_ROBERTA:

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+TESTS = os.path.join(ROOT, "tests")
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)          # tests/depth_envelope.py (helper shared by test_gpu_depth.py and the report generator)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -298,7 +298,7 @@ def test_config4_extract_train_eval_end_to_end(tmp_path, capsys):
     assert all(r[1] in HD.CLASS_LETTERS and len(r) == 10 and all(np.isfinite(float(x)) for x in r[2:]) for r in rows[1:])
 
 
-@pytest.mark.parametrize("family,mode", [("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16a"), ("hubert", "f16a"),
+@pytest.mark.parametrize("family,mode", [("wavlm", "f16x"), ("hubert", "f16x"), ("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16a"), ("hubert", "f16a"),
                                          ("wavlm", "f16q"), ("hubert", "f16q"), ("wavlm", "f16")])
 def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, capsys, family, mode):
     """Next row 8f-4 end to end (preprocessing/preprocess_speech_pretrained.py:108-177): a PEFT-wrapped checkpoint --

@@ -91,7 +91,7 @@ def _speech_config(ssl_type, batch, seed, oracle_utts=(0,)):
     del enc32, hs32, kept32
     torch.cuda.empty_cache()
     worst = {}
-    for mode in ("bf16", "f16", "f16a"):
+    for mode in ("bf16", "f16", "f16a", "f16x"):
         enc16, hs16, kept16 = run(mode)
         w = 0.0
         for g in range(2):
@@ -104,12 +104,13 @@ def _speech_config(ssl_type, batch, seed, oracle_utts=(0,)):
         del enc16, hs16, kept16
         torch.cuda.empty_cache()
     print(f"{ssl_type} B={batch} x 10 s: fp32x vs oracle {worst32:.3e}; vs fp32x (4 utterances, all states): "
-          f"bf16 {worst['bf16']:.3e}, f16 {worst['f16']:.3e}, f16a {worst['f16a']:.3e}")
+          f"bf16 {worst['bf16']:.3e}, f16 {worst['f16']:.3e}, f16a {worst['f16a']:.3e}, f16x {worst['f16x']:.3e}")
     assert worst32 < TOL_PARITY, worst32
     assert worst["bf16"] < TOL_BF16, worst
-    for m in ("f16", "f16a"):                                             # within 1e-3 of the oracle (triangle bound)
+    for m in ("f16", "f16a", "f16x"):                                     # within 1e-3 of the oracle (triangle bound)
         assert worst[m] + worst32 < TOL_PARITY, (m, worst)
-    assert worst["f16a"] < worst["f16"], worst                            # the drivers' default is the tighter one at full size too
+    assert worst["f16a"] < worst["f16"], worst
+    assert worst["f16x"] < 1e-4, worst                                    # the drivers' default (round 4): fp32x-grade at full size (both are fp32-grade splits)
 
 
 def test_config1_wavlm_large_16x10s_timed_path():

@@ -1,0 +1,41 @@
+"""Parity of the numerics modes at FULL depth under the stress weights (-m gpu; helper + report generator: tests/depth_envelope.py).
+
+Every stress fixture under tests/golden/ has 2-3 layers; the reference runs 24 (WavLM-large) and 48 (HuBERT-xlarge) in fp32
+(preprocessing/preprocess_speech.py:50,66,111-114) and every rounding inside an attention block is amplified by the later layers'
+softmax.  Measured in round 4 (profiles/r04_depth_envelope.txt, error form of test_gpu_e2e.py, all L + 1 states, one 10 s utterance
+and a ragged 3 s + 10 s pair against oracle.ssl_oracle.speech_hidden_states):
+
+  * the fp32 REFERENCE itself is only as good as its conditioning: against the same formulas in float64 it sits at 9e-7 on Gaussian
+    weights, 2.7e-5 with the q / k projections x2 (logits x4), 5e-4 at x2.5 and 0.22 at x4 (the tiny fixtures' "sharp" setting is
+    chaotic at depth: no implementation, the reference on another BLAS included, reproduces it).  The gate cases here are the ones
+    where the reference is well defined (<= 5e-5): sharp x2, outlier channels, row-mean offsets, LoRA-scaled q / v;
+  * "f16x" (3 products everywhere on fp16 hi + lo planes, the drivers' default since round 4): <= 1.0e-4 on every gate case;
+  * "fp32x" (bf16 hi + lo): <= 8e-4 (sharp x2 7.9e-4 / 4.8e-4, LoRA 7.4e-4 / 6.9e-4): inside the gate, little margin;
+  * "f16a" (round 3's default: single-product fp16 feed-forward): 3.7e-3 / 2.9e-3 under sharp attention -- the feed-forward's rounding,
+    benign in 2-3 layers, is amplified by 24-48: it LEAVES the gate, which is why it is no longer the default; <= 6e-4 elsewhere.
+"""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GATE = 1e-3
+CASES = [("wavlm", "sharp2"), ("wavlm", "outliers"), ("wavlm", "rowmean"), ("wavlm", "lora"),
+         ("hubert", "sharp2"), ("hubert", "rowmean"), ("hubert", "lora")]
+
+
+@pytest.mark.parametrize("model,kind", CASES)
+def test_full_depth_stress_envelope(model, kind):
+    import depth_envelope as DE
+    modes = ("f16x", "fp32x", "f16a") if model == "wavlm" else ("f16x", "fp32x")
+    res = DE.envelope(model, kind, modes)
+    worst = {k: max(v) for k, v in res.items()}
+    print(f"{DE.MODELS[model]} stress={kind}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    for mode in ("f16x", "fp32x"):                       # the parity-grade modes hold north_star's 1e-3 at the depth they ship at
+        assert worst[mode] < GATE, (model, kind, mode, worst)
+        if kind == "outliers":                           # ... and on the ordinary channels' own scale beside the 800-sized ones
+            assert worst[mode + ":ordinary"] < GATE, worst
+    assert worst["f16x"] < 2.5e-4, worst                 # the default keeps a 4x margin (measured <= 1.0e-4)
+    assert worst["f16x"] <= worst["fp32x"] * 1.05, worst # 22-bit operands are never worse than 16-bit ones at the same cost
+    if "f16a" in worst:
+        # the documented envelope of the faster mode: parity everywhere except under sharp attention at depth
+        assert worst["f16a"] < (1e-2 if kind == "sharp2" else GATE), worst
