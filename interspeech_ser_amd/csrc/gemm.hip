@@ -57,8 +57,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // WM x WN waves, each TM x TN MFMA tiles of 16x16; BK = K tile; ST = ring stages.
 // OM: format of the out_act copy (== MODE unless the launch converts, e.g. an FP32X stem GEMM feeding FP16 layers).
-// PERSIST (round 3 experiment, SER_GEMM_PERSIST=1): the launch has only as many blocks as are resident at once and each walks several tiles.
-template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE, bool PERSIST = false>
+// (Round 3's persistent form -- only the resident blocks are launched and each walks several tiles -- measured -8 % on the step and was
+// removed from the kernel in round 4; DESIGN.md section 10 keeps the record.)
+template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
 __global__ __launch_bounds__(64 * WM * WN, 2)
 void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -87,16 +88,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 
     const int ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;
-    // Tile loop.  A normal launch has one block per tile (no loop is compiled).  A PERSIST launch has as many blocks as fit the chip at
-    // once and every block walks tiles vb, vb + gridDim.x, ...; between two tiles the previous epilogue's stores are drained (gfx950 counts
-    // stores in vmcnt, and the ring below waits on COUNTED vmcnt for its LDS-DMA) and every wave has left the previous tile's LDS reads.
-    int vb = blockIdx.x;
-    do {
-    if (PERSIST && vb != (int)blockIdx.x) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    int bid = vb;
+    int bid = blockIdx.x;
     {   // bijective XCD remap: blocks with equal (bid & 7) share an L2
         const int nwg = ntm * ntn;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -665,15 +657,22 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         if (d && wave == 0 && lane == 0 && blockIdx.y == 0) d[131072 + blockIdx.x * 4 + 2] = t2;
     }
 #endif
-    } while (PERSIST && (vb += gridDim.x) < ntm * ntn);   // tile loop
 }
+
+// Tile-selection thresholds are constants in the product build; `make EXPERIMENTS=1` turns them back into the environment knobs the
+// A/B scripts under tools/ set (SER_GEMM_T256_MIN, SER_GEMM_FORCE, ...).
+#ifdef SER_EXPERIMENTS
+#define SER_KNOB(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atol(e_) : (long)(dflt); }())
+#else
+#define SER_KNOB(name, dflt) ((long)(dflt))
+#endif
 
 // ------------------------------------------------------------------------------------------------
 enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN512_M64 = 4, CFG_LN512_M32 = 5, CFG_128x64 = 6 };
 
-template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE, bool PERSIST = false>
+template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
 static hipError_t launch_mode(const ser_gemm_args* a, dim3 grid, dim3 block, int LDS, hipStream_t s) {
-    auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, MODE, LNEPI, OM, PERSIST>;
+    auto k = ser_gemm_kernel<WM, WN, TM, TN, BK, ST, MODE, LNEPI, OM>;
     // per instantiation; the drivers launch from several host threads: an atomic flag (two threads may both make the
     // idempotent call, neither reads a half-written flag)
     static std::atomic<bool> ready{false};
@@ -695,18 +694,6 @@ static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     hipError_t e = hipSuccess;
-    if constexpr (!X32 && !LNEPI && BN >= 128) {
-        // SER_GEMM_PERSIST=1 (A/B knob, default 0; bf16 launches of the dense tiles only): launches with more tiles than fit the chip at once
-        // start only the resident blocks, which then walk the tiles
-        static const int persist = [] { const char* e = getenv("SER_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
-        const int per_cu = LDS > 80 * 1024 ? 1 : 2;
-        if (persist && a->groups == 1 && a->mode == SER_MODE_BF16 && grid.x > 256u * per_cu) {
-            grid.x = 256u * per_cu;
-            e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_BF16, LNEPI, SER_MODE_BF16, true>(a, grid, block, LDS, s);
-            if (e != hipSuccess) return ser_fail((int)e, "ser_gemm: cannot raise dynamic LDS to %d", LDS);
-            return ser_check_launch("ser_gemm");
-        }
-    }
     if constexpr (X32) {
         if constexpr (!LNEPI) {
             if (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16)      // output projection of "f16a": 3 products, one-plane copy for FC1
@@ -746,7 +733,7 @@ static int pick_cfg(const ser_gemm_args* a) {
         // Row-complete LayerNorm tiles are BM x 512.  The last conv layers have few rows (M = 16k / 8k / 4k for eight
         // 10 s utterances): 128-row tiles would leave half to 7/8 of the CUs idle, so the tile gets shorter until
         // the grid covers the chip (measured per layer with tools/gemm_by_layer.py).
-        static const int force_bm = [] { const char* e = getenv("SER_GEMM_LN_BM"); return e ? atoi(e) : 0; }();
+        static const int force_bm = (int)SER_KNOB("SER_GEMM_LN_BM", 0);
         const int bm = force_bm ? force_bm : (a->M >= 200 * 128 ? 128 : (a->M >= 200 * 64 ? 64 : 32));
         return bm == 128 ? CFG_LN512 : (bm == 64 ? CFG_LN512_M64 : CFG_LN512_M32);
     }
@@ -756,6 +743,7 @@ static int pick_cfg(const ser_gemm_args* a) {
     // rounds of blocks (N = 4096, conv layers) because it halves the L2->LDS bytes per FLOP.
     // In the real step (two utterance groups in flight) 256x256 already pays from ~200 tiles (QKV and FC1
     // at M = 3992): 9.6 -> 9.1 ms per step, A/B on one device.
+#ifdef SER_EXPERIMENTS
     {   // experiments: SER_GEMM_FORCE="N:K:cfg[,N:K:cfg...]" pins the tile config of matching launches (tools/)
         struct Rule { int n, k, cfg; };
         static Rule rules[8];
@@ -774,20 +762,18 @@ static int pick_cfg(const ser_gemm_args* a) {
         for (int i = 0; i < nrules; ++i)
             if (rules[i].n == a->N && rules[i].k == a->K && rules[i].cfg >= 0 && rules[i].cfg <= CFG_256x256) return rules[i].cfg;
     }
+#endif
     const long t256x256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
-    static const long t256_min = [] {                   // tuning knob (tools/): SER_GEMM_T256_MIN=<tiles>
-        const char* e = getenv("SER_GEMM_T256_MIN");
-        return e ? atol(e) : 150L;                      // 200 before the ping-pong schedule; XLS-R-2B's QKV (184 tiles at 4 x 10 s): +3.2 % on its step
-    }();
+    static const long t256_min = SER_KNOB("SER_GEMM_T256_MIN", 150);      // 200 before the ping-pong schedule; XLS-R-2B's QKV (184 tiles at 4 x 10 s): +3.2 % on its step
     if (a->N >= 256 && t256x256 >= t256_min) return CFG_256x256;
     // grouped positional conv: 64 output channels per group -> a 128x64 tile wastes no MFMA columns
-    static const int n64 = [] { const char* e = getenv("SER_GEMM_N64"); return e ? atoi(e) : 1; }();
+    static const int n64 = (int)SER_KNOB("SER_GEMM_N64", 1);
     if (n64 && a->N <= 64) return CFG_128x64;
     // Deep-K, narrow-N GEMMs (FC2: N = D, K = 4D) that are too small for the 256x256 tile: 256x128 tiles are SLOWER
     // in isolation (52 -> 64 us at M = 3992: only 128 blocks) but +1.5 % on the real step in five A/B pairs -- the
     // launch then occupies half the CUs for its whole (long) K loop and the other utterance group's kernels own the
     // other half, instead of both time-slicing every CU.  The shallow out-projection (K = D) loses with it.
-    static const int deepk = [] { const char* e = getenv("SER_GEMM_DEEPK_256x128"); return e ? atoi(e) : 1; }();
+    static const int deepk = (int)SER_KNOB("SER_GEMM_DEEPK_256x128", 1);
     if (deepk && a->groups == 1 && a->K >= 2048 && a->N >= 128 && a->M >= 512) return CFG_256x128;
     return CFG_128x128;
 }
@@ -844,16 +830,16 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         if (a->ln_gamma) return launch_cfg<2, 4, 4, 8, 32, 2, true, true>(a, s);
         // grouped positional conv (<= 64 output channels per group): 128x64 tiles of 32x64 wave tiles, like the bf16 path's -- the
         // 128x128 tile below computes 64 dead columns per group (fp32x pos-conv: 360 us against 100 us in bf16)
-        static const int x32_n64 = [] { const char* e = getenv("SER_GEMM_N64"); return e ? atoi(e) : 1; }();
+        static const int x32_n64 = (int)SER_KNOB("SER_GEMM_N64", 1);
         if (x32_n64 && a->N <= 64) return launch_cfg<4, 1, 2, 4, 32, 2, false, true>(a, s);
         // Large grids: 256x128 tiles of 64x64 wave tiles on a 32-deep, 3-stage ring (144 KiB): 16 fragments feed 48 MFMAs per
         // k-step (0.33 LDS fragment reads per MFMA against 0.5 for the 32x64 wave tile below), one ping-pong phase per K tile
-        static const long x32_256_min = [] { const char* e = getenv("SER_GEMM_X32_256_MIN"); return e ? atol(e) : 100L; }();   // 100: M = 3992 out-proj / FC2 (128 tiles) gain, M = 1996 ones (64 tiles) lose
+        static const long x32_256_min = SER_KNOB("SER_GEMM_X32_256_MIN", 100);   // 100: M = 3992 out-proj / FC2 (128 tiles) gain, M = 1996 ones (64 tiles) lose
         const long t256x128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128) * a->groups;
         // Largest grids (round 3): 256x256 tiles of 64x128 wave tiles, both planes of a 32-deep K tile per stage, 2 stages (128 KiB):
         // 24 fragments feed 96 MFMAs per K tile (0.25 LDS fragment reads per MFMA, half the L2 -> LDS bytes per product of the
         // 256x128 tile), the weight fragments taken in two halves like the LayerNorm tile's (PPW).  From SER_GEMM_X32_SQ_MIN tiles.
-        static const long x32_sq_min = [] { const char* e = getenv("SER_GEMM_X32_SQ_MIN"); return e ? atol(e) : 150L; }();
+        static const long x32_sq_min = SER_KNOB("SER_GEMM_X32_SQ_MIN", 150);
         const long t256sq = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->groups;
         // Measured on the step (two A/B pairs, one box): the packed QKV projection on it f16a 1 110 / 1 114 -> 1 134 / 1 130 utt/s; FC1 too
         // (its GELU epilogue on 128 accumulators + 64 spilled bias / column-sum registers) gives the gain back: fp32x 848 -> 846.

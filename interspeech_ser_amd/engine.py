@@ -51,10 +51,7 @@ _DTYPE = {_lib.MODE_BF16: torch.bfloat16, _lib.MODE_FP32X: torch.bfloat16, _lib.
 # A/B knob (tools/): SER_NO_SHIFT=1 turns the shifted operand copy of the encoder layers off (state 0 is still centred)
 import os as _os
 _NO_SHIFT = _os.environ.get("SER_NO_SHIFT", "0") == "1"
-# A/B knob (tools/): SER_SPLIT_GATE=1 gives WavLM's 2H gate columns their own small launch so that the packed projection is exactly
-# 12 column tiles of 256 wide instead of 13 (N = 3D + 32).  Measured (round 3, two A/B pairs): bf16 1 941 / 1 940 -> 1 933 / 1 937 utt/s,
-# f16a 1 103 -> 1 098: the extra launch (its own deferred-LayerNorm prologue, 63 blocks) costs what the 13th tile column does.  Default 0.
-_SPLIT_GATE = _os.environ.get("SER_SPLIT_GATE", "0") == "1"
+# (Round 3's SER_SPLIT_GATE -- the 2H gate columns as their own narrow launch -- measured -0.3 % and was removed in round 4: DESIGN.md section 10.)
 # WavLM's gate pre-activations: computed by ser_attention from the layer input's operand copy (ser_attention_args.gate_x; default), or
 # 2H extra columns of the packed projection (SER_GATE_IN_ATTN=0, rounds 1-3: a 13th 256-wide column tile for 32 columns).  Measured on the
 # step (tools/gate_in_attn_ab.sh, two A/B pairs per build, one box; profiles/r03_gate_in_attn_ab.txt): bf16 2 018 / 2 018 -> 2 029 / 2 029
@@ -437,8 +434,6 @@ class _EncoderBase:
         if self.qk_mode is None:
             self._gemm(pl["xa"], lay["qkv"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
                        col_scale_end=D, ln_mean=ln_mean, mode=self.attn_mode, lnstat_out=lnstat)
-            if "gate" in lay:                       # WavLM gate pre-activations: 2H columns behind v, their own narrow launch
-                self._gemm(pl["xa"], lay["gate"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], out_col=3 * D, mode=self.attn_mode)
             return
         self._gemm(pl["xa"], lay["qk"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
                    col_scale_end=D, ln_mean=ln_mean, mode=self.qk_mode, lnstat_out=lnstat)
@@ -575,11 +570,7 @@ class _EncoderBase:
             ws.append(torch.cat([wg, torch.zeros(pad, D, device=wdev)], 0))
             bs.append(torch.cat([torch.stack([b8[:4].sum(), b8[4:].sum()]).repeat(H), torch.zeros(pad, device=wdev)]))
             lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
-        if self.qk_mode is None and gate and _SPLIT_GATE:
-            # 3D columns = whole 256-wide tiles; the 2H (+ pad) gate columns would cost a 13th column tile for 32 columns
-            lay["qkv"] = self._linear_ln(torch.cat(ws[:3], 0), torch.cat(bs[:3], 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=self.attn_mode)
-            lay["gate"] = self._linear_ln(ws[3], bs[3], sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=self.attn_mode)
-        elif self.qk_mode is None:
+        if self.qk_mode is None:
             lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=self.attn_mode)
         else:
             # logit path [q | k | gate] on fp16 hi + lo planes (3 products), [v] on one fp16 plane
