@@ -48,7 +48,10 @@ extern "C" { void* ser_attn_dbg_ptr = nullptr; }
 // (Round 3's persistent form -- resident blocks walking the items -- and its 8-wave form measured +- 0 / -1.2 % on the step and were
 // removed from the build in round 4: DESIGN.md section 10 keeps the record.)
 template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
-__global__ __launch_bounds__(64 * NWV, (DHP == 128 && mode_traits<MODE>::planes == 2) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2))
+// waves per SIMD the registers leave room for: two everywhere (round 4: the 96-wide two-plane forms and the 128-wide ones WITHOUT a bias table
+// fit 256 registers unspilled -- head dim 80 in the 3-product modes 98.9 -> 49.9 us per 8 x 499 frames) except the 128-wide two-plane form
+// with a bias table (208 spilled registers at two; no encoder uses it: WavLM's head dim is 64)
+__global__ __launch_bounds__(64 * NWV, (DHP == 128 && mode_traits<MODE>::planes == 2 && TBL) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
     // NP: planes of Q and K (the logit path S = K Q^T: 3 products when 2), NPV: planes of V and P.  FP16Q (the "f16q" numerics
@@ -670,7 +673,9 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
         if (bias2d_ld < max_frames || (bias2d_ld % ABKV))
             return ser_fail(-12, "ser_attention: bias2d_ld=%lld must be a multiple of %d and >= max_frames", (long long)bias2d_ld, ABKV);
     }
-    const int dhp = dh <= 64 ? 64 : 128;
+    // padded head dim of the LDS images and MFMA loops: 64, 96 (head dims 72 .. 96: HuBERT-xlarge's 80 runs 6 + 6 k-steps and 3 output column
+    // blocks instead of the 8 + 8 and 4 of the 128-wide form it used through round 3) or 128
+    const int dhp = dh <= 64 ? 64 : (dh <= 96 ? 96 : 128);
     const int np = (mode == SER_MODE_FP32X || mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q) ? 2 : 1;      // planes of q / k
     const int npv = (mode == SER_MODE_FP32X || mode == SER_MODE_FP16X) ? 2 : 1;                                 // planes of v
     const int nwv = 4;
@@ -728,17 +733,19 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     if (bias2d)
         return mode == SER_MODE_FP32X ? launch_attention<64, SER_MODE_FP32X, true, false, 4, true>(p, grid, lds, s)
                                       : launch_attention<64, SER_MODE_BF16, true, false, 4, true>(p, grid, lds, s);
-    if (mode == SER_MODE_FP16) return dhp == 64 ? SER_ATTN(64, SER_MODE_FP16) : SER_ATTN(128, SER_MODE_FP16);
+#define SER_ATTN_D(M_) (dhp == 64 ? SER_ATTN(64, M_) : (dhp == 96 ? SER_ATTN(96, M_) : SER_ATTN(128, M_)))
+    if (mode == SER_MODE_FP16) return SER_ATTN_D(SER_MODE_FP16);
     if (mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q) {      // "f16a" / "f16q": the host always pre-scales q; only the PRE forms are built
         if (!pre) return ser_fail(-13, "ser_attention: FP16X / FP16Q need a pre-scaled q (scale <= 0)");
 #define SER_ATTN_X(D_, M_) (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s))
-        if (mode == SER_MODE_FP16X) return dhp == 64 ? SER_ATTN_X(64, SER_MODE_FP16X) : SER_ATTN_X(128, SER_MODE_FP16X);
-        return dhp == 64 ? SER_ATTN_X(64, SER_MODE_FP16Q) : SER_ATTN_X(128, SER_MODE_FP16Q);
+#define SER_ATTN_XD(M_) (dhp == 64 ? SER_ATTN_X(64, M_) : (dhp == 96 ? SER_ATTN_X(96, M_) : SER_ATTN_X(128, M_)))
+        if (mode == SER_MODE_FP16X) return SER_ATTN_XD(SER_MODE_FP16X);
+        return SER_ATTN_XD(SER_MODE_FP16Q);
+#undef SER_ATTN_XD
 #undef SER_ATTN_X
     }
-    if (dhp == 64 && np == 1) return SER_ATTN(64, SER_MODE_BF16);
-    if (dhp == 64) return SER_ATTN(64, SER_MODE_FP32X);
-    if (np == 1) return SER_ATTN(128, SER_MODE_BF16);
-    return SER_ATTN(128, SER_MODE_FP32X);
+    if (np == 1) return SER_ATTN_D(SER_MODE_BF16);
+    return SER_ATTN_D(SER_MODE_FP32X);
+#undef SER_ATTN_D
 #undef SER_ATTN
 }

@@ -53,12 +53,22 @@ extern "C" { extern void* ser_attn_dbg_ptr; }
 #ifdef SER_ATTN_DBG
 static __constant__ int ser_attn_dbg_block_dev = 100;
 #endif
+// LDS images of a K / V tile, [key][DHP x 16 bit] rows.  DHP = 64 / 128 (128- / 256-byte rows): XOR swizzles of the 16-byte chunk (K, read
+// by rows with ds_read_b128) and of the 64-byte unit (V, read transposed with ds_read_b64_tr_b16).  DHP = 96 (192-byte rows = 48 banks,
+// head dims 72 .. 96: HuBERT-xlarge's 80): 12 chunks per row are not a power of two, so the K chunk is ROTATED by (key >> 2) & 3 --
+// the 16 rows of every ds_read_b128 lane group then start on 16 distinct 4-bank slots (12 r + c' mod 16, enumerated for all groups and
+// chunks) -- and V needs no swizzle at all: four consecutive keys' units already sit on four different bank quarters ((3 r + u) mod 4).
 template <int DHP>
 __device__ __forceinline__ int k_swz(int key, int chunk) {
+    if (DHP == 96) {
+        const int c = chunk + ((key >> 2) & 3);
+        return c >= 12 ? c - 12 : c;
+    }
     return DHP == 64 ? (chunk ^ ((key >> 1) & 7)) : (chunk ^ (key & 15));
 }
 template <int DHP>
 __device__ __forceinline__ int v_unit_swz(int key, int unit) {
+    if (DHP == 96) return unit;
     return DHP == 64 ? (unit ^ ((key >> 1) & 1)) : (unit ^ (key & 3));
 }
 

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interspeech_ser_amd import _lib as L
 DEV = "cuda:0"; st = torch.cuda.current_stream().cuda_stream
 NAMES = {1: "BF16", 3: "FP16", 5: "FP16Q", 4: "FP16X", 2: "FP32X"}
-for (B, T, H, dh, bias) in ((8, 499, 16, 64, True), (16, 499, 16, 64, True), (8, 1500, 20, 64, False), (8, 499, 16, 80, False)):
+for (B, T, H, dh, bias) in ((8, 499, 16, 64, True), (16, 499, 16, 64, True), (8, 1500, 20, 64, False), (8, 499, 16, 80, False), (8, 499, 16, 120, False), (8, 1500, 20, 64, False)):
     D = H * dh
     M = B * T
     ld = 3 * D + 32
