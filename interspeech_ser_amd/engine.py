@@ -197,6 +197,11 @@ class HiddenStates:
     def frames(self, b: int) -> int:
         return self.frame_offs[b + 1] - self.frame_offs[b]
 
+    def max_abs(self) -> torch.Tensor:
+        """max |value| over the computed states, as a 0-d device tensor (one reduction kernel, enqueued on the current stream).
+        The fp16-plane numerics modes keep operand copies of the residual stream in fp16 (range 65 504): the drivers watch this."""
+        return self.states[: self.computed, : self.frame_offs[-1]].abs().amax()
+
 
 class _EncoderBase:
     def __init__(self, geo: EncoderGeometry, device, mode: str):

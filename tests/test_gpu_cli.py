@@ -368,6 +368,43 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
     assert worst < (5e-3 if mode in ("f16", "f16q") else 1e-3), worst
 
 
+def test_fp16_range_guard_fails_the_files_instead_of_clipping(tmp_path, capsys):
+    """The default numerics mode keeps operand copies on fp16 planes (range 65 504).  A checkpoint whose residual stream leaves that
+    range (here: a feed-forward output bias of 1e5 in one channel, 100x the "massive activation" of the outlier fixtures) must not
+    yield silently clipped features: the driver watches max|hidden state| on the device and reports every file of such a batch as
+    ``Failed to process ...`` with the way out (--mode fp32x: bf16 planes, fp32 range), where the same checkpoint extracts fine."""
+    from safetensors.torch import save_file
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import apply_stress, synthetic_state_dict
+    geo = C.TINY_WAVLM
+    sd = apply_stress(synthetic_state_dict(geo, 41), geo, "outliers")
+    sd["encoder.layers.0.feed_forward.output_dense.bias"][7] += 1.0e5
+    ck = tmp_path / "huge.safetensors"
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ck))
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    for i, n in enumerate((16000, 9000, 12000)):
+        write_wav(wav_dir / f"u{i}.wav", synth(70 + i, n))
+    C._REGISTRY["tiny-range-test"] = geo
+    try:
+        out = tmp_path / "pt_f16x"
+        assert driver.run_speech(["--ssl_type", "tiny-range-test", "--wav_dir", str(wav_dir), "--save_path", str(out), "--checkpoint", str(ck),
+                                  "--use_n_layer", "--n_layer", "-1"]) == 0                      # default mode: f16x
+        log = capsys.readouterr().out
+        assert log.count("Failed to process") == 3 and "fp16 operand range" in log and "--mode fp32x" in log, log
+        assert os.listdir(out) == []
+        out2 = tmp_path / "pt_fp32x"
+        assert driver.run_speech(["--ssl_type", "tiny-range-test", "--wav_dir", str(wav_dir), "--save_path", str(out2), "--checkpoint", str(ck),
+                                  "--use_n_layer", "--n_layer", "1", "--mode", "fp32x"]) == 0
+        log = capsys.readouterr().out
+        assert "Failed to process" not in log and sorted(os.listdir(out2)) == ["u0.pt", "u1.pt", "u2.pt"]
+        t = torch.load(out2 / "u0.pt")
+        assert float(t.abs().max()) > 9.0e4                                                     # the value the fp16 planes could not hold
+    finally:
+        C._REGISTRY.pop("tiny-range-test")
+
+
 def test_whisper_lora_checkpoint_through_the_driver(tmp_path, capsys):
     """preprocessing/preprocess_whisper_pretrained.py:115-190: a PEFT-wrapped Whisper (``whisper.base_model.model.*``, adapters on
     q_proj / v_proj of encoder AND decoder, a classifier head) saved with torch.save as a ``.pt`` state dict, extracted with the

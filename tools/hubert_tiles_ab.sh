@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the experiments build: make -C interspeech_ser_amd/csrc clean all EXPERIMENTS=1 -- the tile-selection knobs are constants in the product library)
 # HuBERT-xlarge (D = 1280: 5 column tiles of 256, 10 of 128) -- tile configurations of the output projection (N = K = 1280) and FC2
 # (N = 1280, K = 5120) forced through SER_GEMM_FORCE="N:K:cfg" (0 = 128x128, 1 = 256x128, 2 = 256x256), same box, the step.
 set -e

@@ -5,11 +5,11 @@
 # (separate passes for FETCH_SIZE / WRITE_SIZE / SQ counters, --kernel-trace only, as the MI355X guide prescribes).
 # Raw output under gpurun_out/prof/, summaries under profiles/<tag>_*.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof
 mkdir -p $OUT profiles
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
-FLAGS="--no-trace --no-cpu-baseline --no-parity --no-e2e"
+FLAGS="--no-trace --no-cpu-baseline --no-parity --no-e2e --other-encoders none"
 stats() {  # name, bench args...
     local name=$1; shift
     rm -rf $OUT/$name                       # rocprofv3 -d accumulates one subdirectory per run: never stamp a stale CSV
@@ -30,7 +30,12 @@ if [ "$2" = "traffic" ]; then   # only the two traffic passes: re-stamp profiles
     echo done; exit 0
 fi
 stats wavlm_large_bf16 --steps 10 || exit 1
+stats wavlm_large_f16x --steps 10 --mode f16x || exit 1
 stats wavlm_large_f16a --steps 10 --mode f16a || exit 1
+# one launch at a time (no graph, one batch, no concurrent branch): the CSV from which roofline.one_launch_at_a_time.avg_launch_us can be
+# reproduced (the other CSVs' averages are inflated by the two branches overlapping under the profiler)
+stats wavlm_large_bf16_one_launch_at_a_time --steps 3 --no-graph --inflight 1 --micro 1 || exit 1
+cp profiles/${TAG}_kernel_stats_wavlm_large_bf16_one_launch_at_a_time.csv profiles/${TAG}_kernel_trace_one_launch_at_a_time_wavlm_large_bf16.csv
 stats hubert_xlarge_bf16 --steps 5 --ssl_type facebook/hubert-xlarge-ll60k || exit 1
 stats xlsr_2b_bf16 --steps 5 --ssl_type facebook/wav2vec2-xls-r-2b --batch 8 || exit 1
 stats whisper_large_v3_bf16 --steps 3 --reps 4 --ssl_type openai/whisper-large-v3 --seconds 30 || exit 1
@@ -40,7 +45,11 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|inflight=2|groups=1"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_sq.err || exit 1
-python3 tools/pmc_sq_summary.py $OUT/pmc_sq profiles/$TAG
+# second SQ pass: what the K loop waits on (LDS issue stalls, vector and matrix instructions executing together)
+rm -rf $OUT/pmc_sq2
+rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE \
+    --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_sq2.err || echo "(second SQ pass not available: $(tail -1 $OUT/pmc_sq2.err))"
+python3 tools/pmc_sq_summary.py $OUT/pmc_sq profiles/$TAG $OUT/pmc_sq2
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_l2.err || exit 1
 python3 tools/pmc_l2_summary.py $OUT/pmc_l2 profiles/$TAG
 # Whisper front end alone against HBM bytes (FETCH/WRITE of the logmel kernels come out of the per-kernel CSV)

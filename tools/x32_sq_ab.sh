@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the experiments build: make -C interspeech_ser_amd/csrc clean all EXPERIMENTS=1 -- the tile-selection knobs are constants in the product library)
 # A/B on one box (env knobs, one build): which two-plane launches take the 256x256 tile (SER_GEMM_X32_SQ_MIN = least number of tiles).
 # 150 (default): packed projection only; 100: the output projection too (128 tiles at M = 7 984: half the chip, like FC2's deep-K tile).
 set -e
