@@ -47,11 +47,16 @@ extern "C" { void* ser_attn_dbg_ptr = nullptr; }
 // reference has no length limit (preprocess_speech.py:47-50 runs whatever librosa.load returns).  Needs PRE and TBL, head dim <= 64.
 // (Round 3's persistent form -- resident blocks walking the items -- and its 8-wave form measured +- 0 / -1.2 % on the step and were
 // removed from the build in round 4: DESIGN.md section 10 keeps the record.)
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
+// OCC (round 4; single-plane 64-wide forms only): the HIGH-OCCUPANCY form -- ONE K/V buffer and fragments read just in time keep the
+// kernel at 128 registers and 28 KiB of LDS (499 frames), i.e. FOUR waves per SIMD / four blocks per CU, so that the 1 024 blocks of a
+// 16-utterance x 16-head x 499-frame launch are resident in ONE round instead of two (40.5 -> 37.0 us; ragged 64..499 frames 34.3 -> 30.5).
+// With at most two blocks per CU to place (8-utterance launches: 512 blocks) the low-occupancy form -- double buffer, all LDS reads of a phase
+// up front, 198 registers -- is the faster one (23.0 against 24.4 us): the launcher picks by grid size.
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false, bool OCC = false>
 // waves per SIMD the registers leave room for: two everywhere (round 4: the 96-wide two-plane forms and the 128-wide ones WITHOUT a bias table
 // fit 256 registers unspilled -- head dim 80 in the 3-product modes 98.9 -> 49.9 us per 8 x 499 frames) except the 128-wide two-plane form
 // with a bias table (208 spilled registers at two; no encoder uses it: WavLM's head dim is 64)
-__global__ __launch_bounds__(64 * NWV, (DHP == 128 && mode_traits<MODE>::planes == 2 && TBL) ? 1 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2))
+__global__ __launch_bounds__(64 * NWV, (DHP == 128 && mode_traits<MODE>::planes == 2 && TBL) ? 1 : (OCC ? 4 : ((DHP == 64 && mode_traits<MODE>::planes == 1) ? SER_ATTN_MINW : 2)))
 void attention_kernel(const AttnParams p) {
     constexpr int NT = 64 * NWV;                // threads per block
     // NP: planes of Q and K (the logit path S = K Q^T: 3 products when 2), NPV: planes of V and P.  FP16Q (the "f16q" numerics
@@ -66,7 +71,8 @@ void attention_kernel(const AttnParams p) {
     constexpr int CPR = DHP / 8;                // 16-byte chunks per row
     constexpr int TILE = ABKV * RS;             // bytes of one K or V plane tile
     constexpr int NCH = ABKV * CPR / NT;        // staged 16-B chunks per thread per plane per operand
-    constexpr bool DB = (NCH * (NP + NPV)) <= 8;   // double-buffer when the register stage is <= 32 VGPRs
+    // double-buffer when the register stage is <= 32 VGPRs (the high-occupancy form: one buffer)
+    constexpr bool DB = !OCC && (NCH * (NP + NPV)) <= 8;
     constexpr int NBUF = DB ? 2 : 1;
     constexpr int BUF = (NP + NPV) * TILE;      // one K+V buffer
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,7 +342,7 @@ void attention_kernel(const AttnParams p) {
         // WIDE (bf16, head dim <= 64): every LDS read of a phase is issued before its first consumer, so a phase
         // pays the LDS latency once; left alone, hipcc re-uses one fragment register and emits
         // read -> wait(0) -> MFMA eight times in a row (measured: 1400 of a tile's 3600 cycles).
-        constexpr bool WIDE = (NP == 1 && DHP == 64);
+        constexpr bool WIDE = !OCC && (NP == 1 && DHP == 64);
         const int cur = DB ? (kt & 1) : 0;
         const char* ldsK = smem + cur * BUF;
         const char* ldsV = ldsK + NP * TILE;
@@ -615,9 +621,9 @@ void attention_kernel(const AttnParams p) {
     }
 }
 
-template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false>
+template <int DHP, int MODE, bool PRE, bool TBL, int NWV = 4, bool B2D = false, bool GB = false, bool OCC = false>
 static int launch_attention(const AttnParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D, GB>;
+    auto k = attention_kernel<DHP, MODE, PRE, TBL, NWV, B2D, GB, OCC>;
     static std::atomic<bool> ready{false};          // several host threads launch (see gemm.hip launch_mode)
     if (lds > 65536 && !ready.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -680,7 +686,13 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     const int npv = (mode == SER_MODE_FP32X || mode == SER_MODE_FP16X) ? 2 : 1;                                 // planes of v
     const int nwv = 4;
     const int nch = ABKV * (dhp / 8) / (64 * nwv);
-    const int nbuf = (nch * (np + npv) <= 8) ? 2 : 1;
+    const int nq_tiles = (max_frames + 32 * nwv - 1) / (32 * nwv);
+    const unsigned nblocks = (unsigned)(((H * B + 7) / 8) * 8 * nq_tiles);
+    // high-occupancy form (see the kernel): single-plane 64-wide launches with more than two blocks per CU to place that fit ONE round at
+    // four per CU (measured: 16 x 16 heads x 300 / 499 frames and the ragged mix gain 8 - 11 %; Whisper's 1 920-block launches run several
+    // rounds either way and LOSE 1 - 3 % on their step with it: left on the low-occupancy form)
+    bool occ = dhp == 64 && np == 1 && !bias2d && nblocks > 2u * 256u && nblocks <= 4u * 256u;
+    int nbuf = (!occ && nch * (np + npv) <= 8) ? 2 : 1;
     // copy stride == 16 (mod 64) floats: the 4 shifted copies x the 4 query phases of a ds_read_b128
     // lane group then land on 16 distinct 4-bank slots (a multiple of 64 made them 2-way conflicts)
     int bias_stride = 0;
@@ -692,7 +704,12 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     // a bias window that does not fit (utterances beyond ~2 min; ~1.5 min in the two-plane modes): the table is read from global
     // memory instead (GB forms: pre-scaled q, head dim <= 64 -- what the WavLM encoders use)
     const bool gbias = table && lds > 160 * 1024 && scale <= 0.f && dhp == 64 && nwv == 4;
-    if (gbias) { bias_stride = 0; lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2; }
+    if (gbias) {                                                  // (the GB forms have no high-occupancy instantiation: double buffer)
+        occ = false;
+        nbuf = (nch * (np + npv) <= 8) ? 2 : 1;
+        bias_stride = 0;
+        lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2;
+    }
     if (lds > 160 * 1024) return ser_fail(-8, "ser_attention: LDS need %zu > 160 KiB (max_frames=%d)", lds, max_frames);
     AttnParams p;
     p.qkv = (const unsigned short*)qkv; p.ld = ld; p.plane = plane_stride;
@@ -719,8 +736,9 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
         if (r <= 0) return r;
     }
 #endif
-#define SER_ATTN(D_, M_) (pre ? (table ? launch_attention<D_, M_, true, true>(p, grid, lds, s) : launch_attention<D_, M_, true, false>(p, grid, lds, s)) \
-                              : (table ? launch_attention<D_, M_, false, true>(p, grid, lds, s) : launch_attention<D_, M_, false, false>(p, grid, lds, s)))
+#define SER_ATTN_O(D_, M_, O_) (pre ? (table ? launch_attention<D_, M_, true, true, 4, false, false, O_>(p, grid, lds, s) : launch_attention<D_, M_, true, false, 4, false, false, O_>(p, grid, lds, s)) \
+                                    : (table ? launch_attention<D_, M_, false, true, 4, false, false, O_>(p, grid, lds, s) : launch_attention<D_, M_, false, false, 4, false, false, O_>(p, grid, lds, s)))
+#define SER_ATTN(D_, M_) SER_ATTN_O(D_, M_, false)
     if (gbias) {
         switch (mode) {
             case SER_MODE_BF16:  return launch_attention<64, SER_MODE_BF16, true, true, 4, false, true>(p, grid, lds, s);
@@ -734,6 +752,7 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
         return mode == SER_MODE_FP32X ? launch_attention<64, SER_MODE_FP32X, true, false, 4, true>(p, grid, lds, s)
                                       : launch_attention<64, SER_MODE_BF16, true, false, 4, true>(p, grid, lds, s);
 #define SER_ATTN_D(M_) (dhp == 64 ? SER_ATTN(64, M_) : (dhp == 96 ? SER_ATTN(96, M_) : SER_ATTN(128, M_)))
+    if (occ) return mode == SER_MODE_FP16 ? SER_ATTN_O(64, SER_MODE_FP16, true) : SER_ATTN_O(64, SER_MODE_BF16, true);
     if (mode == SER_MODE_FP16) return SER_ATTN_D(SER_MODE_FP16);
     if (mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q) {      // "f16a" / "f16q": the host always pre-scales q; only the PRE forms are built
         if (!pre) return ser_fail(-13, "ser_attention: FP16X / FP16Q need a pre-scaled q (scale <= 0)");
@@ -748,4 +767,5 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     return SER_ATTN_D(SER_MODE_FP32X);
 #undef SER_ATTN_D
 #undef SER_ATTN
+#undef SER_ATTN_O
 }
