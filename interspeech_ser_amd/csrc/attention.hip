@@ -23,6 +23,9 @@
 //   * LDS images: K rows XOR-swizzled for conflict-free ds_read_b128 row reads, V 64-byte
 //     units XOR-swizzled so the 4 keys of a transposed read hit 4 different bank quarters.
 //   * FP32X mode: every product is the 3-term bf16 split (hi*hi + lo*hi + hi*lo).
+//   * round 4: a 96-wide form for head dims 72 .. 96, two waves per SIMD for every two-plane form that fits 256 registers, and a
+//     high-occupancy arm (OCC: one K/V buffer, fragments read just in time, 128 registers, four blocks per CU) that the launcher picks
+//     for single-plane 64-wide launches of 513 .. 1 024 blocks -- see the template's comment and DESIGN.md section 5.
 #include "attn_common.h"
 #include <stdlib.h>
 #include <type_traits>
