@@ -24,6 +24,10 @@ def _worker(rank, world, port, out_dir):
     sd, dt, nbytes = D.broadcast_state_dict(sd)
     assert nbytes == sum((v.numel() + 3) // 4 * 4 for v in sd.values()) * 4 and dt >= 0     # entries padded to 16-byte boundaries
     digest = state_dict_digest(sd)
+    import bench                                     # the record bench.py prints at N > 1: read from the live process group
+    rec = bench.collective_record(world, dt, nbytes)
+    assert rec["backend"] == "gloo" and rec["ranks"] == world and rec["bytes"] == nbytes and rec["GB_per_s"] is not None, rec
+    assert bench.collective_record(1, 0.0, 0)["backend"] is None
     n = D.broadcast_int(17 if rank == 0 else -1)
     files = [f"f{i}" for i in range(9)]
     mine = D.shard_files(files, [100 - i for i in range(9)], rank, world)
