@@ -20,13 +20,13 @@ pytestmark = pytest.mark.gpu
 
 GATE = 1e-3
 CASES = [("wavlm", "sharp2"), ("wavlm", "outliers"), ("wavlm", "rowmean"), ("wavlm", "lora"),
-         ("hubert", "sharp2"), ("hubert", "rowmean"), ("hubert", "lora")]
+         ("hubert", "sharp2"), ("hubert", "lora")]           # (hubert rowmean / outliers: in profiles/r04_depth_envelope.txt; the suite's time budget)
 
 
 @pytest.mark.parametrize("model,kind", CASES)
 def test_full_depth_stress_envelope(model, kind):
     import depth_envelope as DE
-    modes = ("f16x", "fp32x", "f16a") if model == "wavlm" else ("f16x", "fp32x")
+    modes = ("f16x", "fp32x", "f16a") if (model == "wavlm" and kind in ("sharp2", "lora")) else ("f16x", "fp32x")
     res = DE.envelope(model, kind, modes)
     worst = {k: max(v) for k, v in res.items()}
     print(f"{DE.MODELS[model]} stress={kind}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
