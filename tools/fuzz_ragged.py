@@ -1,7 +1,7 @@
 """Randomised ragged-batch shake-out (GPU box, a few minutes): tiny geometries of the three speech families, random batch sizes
 and utterance lengths through ONE long-lived encoder per (family, mode) -- arenas grow and shrink, command lists are patched --
 checking (1) batched == batch-of-one bit for bit on a sampled utterance, (2) the command-list path == the launch-by-launch path,
-(3) fp32x / f16a / f16q / f16 / bf16 within their tolerances of the CPU oracle on a sampled utterance."""
+(3) f16x / fp32x / f16a / f16q / f16 / bf16 within their tolerances of the CPU oracle on a sampled utterance."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ from interspeech_ser_amd.weights import synthetic_state_dict
 from oracle import ssl_oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-TOL = {"fp32x": 1e-3, "f16a": 1e-3, "f16q": 1e-3, "f16": 1e-3, "bf16": 3e-2}
+TOL = {"f16x": 1e-3, "fp32x": 1e-3, "f16a": 1e-3, "f16q": 1e-3, "f16": 1e-3, "bf16": 3e-2}
 MODES = tuple(TOL)
 fams = [("wavlm", C.TINY_WAVLM), ("hubert", C.TINY_HUBERT), ("wav2vec2", C.TINY_WAV2VEC2)]
 encs = {}

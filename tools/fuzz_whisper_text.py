@@ -11,13 +11,13 @@ from interspeech_ser_amd.weights import synthetic_state_dict
 from oracle import ssl_oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-TOL = {"fp32x": 1e-3, "f16": 1e-3, "f16a": 1e-3, "f16q": 1e-3, "bf16": 3e-2}
+TOL = {"fp32x": 1e-3, "f16": 1e-3, "f16a": 1e-3, "f16q": 1e-3, "f16x": 1e-3, "bf16": 3e-2}
 rel = lambda a, b: float((a - b).abs().max() / max(1.0, float(b.abs().max())))
 encs, worst, n = {}, {}, 0
 t_end = time.time() + budget
 while time.time() < t_end:
     fam = ("whisper", "roberta", "deberta")[int(rng.integers(3))]
-    mode = ("fp32x", "bf16", "f16", "f16a", "f16q")[int(rng.integers(5 if fam == "whisper" else 2))]
+    mode = ("fp32x", "bf16", "f16x", "f16", "f16a", "f16q")[int(rng.integers(6 if fam == "whisper" else 2))]
     geo = {"whisper": C.TINY_WHISPER, "roberta": C.TINY_ROBERTA, "deberta": C.TINY_DEBERTA}[fam]
     key = (fam, mode)
     if key not in encs:

@@ -10,7 +10,7 @@ from oracle import ssl_oracle as O
 geo = C.TINY_WAVLM
 sd = synthetic_state_dict(geo, 1)
 rng = np.random.default_rng(0)
-for mode in ("fp32x", "bf16"):
+for mode in ("f16x", "fp32x", "bf16"):
     enc = SpeechEncoder(geo, sd, "cuda:0", mode=mode)
     for secs in (60, 110, 130, 300):
         w = (0.1 * rng.standard_normal(16000 * secs)).astype(np.float32)
