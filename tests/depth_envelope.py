@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MODELS = {"wavlm": "microsoft/wavlm-large", "hubert": "facebook/hubert-xlarge-ll60k", "xlsr": "facebook/wav2vec2-xls-r-2b"}
+MODELS = {"wavlm": "microsoft/wavlm-large", "hubert": "facebook/hubert-xlarge-ll60k", "xlsr": "facebook/wav2vec2-xls-r-2b",
+          "whisper": "openai/whisper-large-v3"}        # whisper: kinds plain / sharpF only (30 s window + a 7.3 s clip, saved rows)
 # "sharpF": q / k projections x F (logits x F^2); F = 4 is weights.apply_stress("sharp"), the tiny fixtures' setting
 KINDS = ("plain", "sharp2", "sharp2.5", "sharp4", "outliers", "rowmean", "lora")
 
@@ -140,6 +141,49 @@ def envelope(model, kind, modes=("f16a", "fp32x"), fp64=False):
     return res
 
 
+def whisper_envelope(kind, modes=("f16x", "fp32x")):
+    """The Whisper-large-v3 encoder (32 layers, 1 500 frames) the same way: a full 30 s window alone and a ragged pair (7.3 s + 30 s),
+    all 33 states over the rows the driver saves (preprocessing/preprocess_whisper.py:49-50,75-76), against oracle.whisper_hidden_states
+    on oracle.whisper_log_mel.  Stress kinds: "plain" and "sharpF" (q and k projections x F; k_proj has no bias)."""
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import WhisperEncoder
+    from interspeech_ser_amd.frontend import whisper_saved_rows
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    from oracle import ssl_oracle as O              # checker only
+    geo = C.geometry_for(MODELS["whisper"])
+    sd = synthetic_state_dict(geo, 0)
+    if kind.startswith("sharp"):
+        f = float(kind[5:] or 4.0)
+        sd = {k: v.clone() for k, v in sd.items()}
+        for i in range(geo.num_layers):
+            for name in ("q_proj.weight", "q_proj.bias", "k_proj.weight"):
+                sd[f"encoder.layers.{i}.self_attn.{name}"] *= f
+    elif kind != "plain":
+        raise ValueError("whisper envelope: kinds plain / sharpF")
+    a, b, c = clip(201, 30.0), clip(202, 7.3), clip(203, 30.0)
+    flat, batches = [a, b, c], [[a], [b, c]]
+    ref, rows = [], []
+    with torch.no_grad():
+        for w in flat:
+            r = whisper_saved_rows(len(w), geo.hidden)
+            ref.append([x[:r] for x in O.whisper_hidden_states(geo, sd, torch.from_numpy(O.whisper_log_mel(w, geo.n_mels)))])
+            rows.append(r)
+    res = {}
+    for mode in modes:
+        enc = WhisperEncoder(geo, sd, "cuda:0", mode=mode)
+        got = []
+        for waves in batches:
+            lengths = [len(w) for w in waves]
+            hs = enc.forward(enc.upload(waves), lengths)
+            torch.cuda.synchronize()
+            for u in range(len(waves)):
+                got.append([hs.utterance(u, layer).cpu() for layer in range(len(hs))])
+        del enc
+        torch.cuda.empty_cache()
+        res[mode] = [max(rel_err(got[u][layer][:rows[u]], ref[u][layer]) for u in range(3)) for layer in range(geo.num_layers + 1)]
+    return res
+
+
 def fmt_row(name, vals, every):
     idx = list(range(0, len(vals), every))
     if idx[-1] != len(vals) - 1:
@@ -161,7 +205,7 @@ def main(argv=None):
     summary = []
     for model in args.models.split(","):
         for kind in args.kinds.split(","):
-            res = envelope(model, kind, modes, fp64=args.fp64)
+            res = whisper_envelope(kind, modes) if model == "whisper" else envelope(model, kind, modes, fp64=args.fp64)
             L = len(next(iter(res.values())))
             every = 4 if L <= 25 else 8
             print(f"{MODELS[model]} ({L - 1} layers), stress = {kind}")
