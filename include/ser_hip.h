@@ -207,13 +207,14 @@ int ser_attention(const void* qkv, int64_t ld, int64_t plane_stride, int q_col, 
                   int gate_col, const float* gru_const /*[H]*/,
                   const int32_t* key_lens /*[B] or NULL: keys >= key_lens[b] are padding (RoBERTa attention_mask)*/,
                   const float* bias2d /*[B][H][max_frames][bias2d_ld] fp32 dense additive bias in the exp2 domain, or NULL
-                                        (DeBERTa, from ser_deberta_bias): uniform-length batches, q pre-scaled, dh <= 64; padded
+                                        (DeBERTa, from ser_deberta_bias): uniform-length batches, q pre-scaled, dh <= 64, modes BF16 / FP32X / FP16X; padded
                                         query rows (q >= key_lens[b]) then come out as the uniform average of all value rows*/,
                   int64_t bias2d_ld,
                   void* stream);
 
 /* next row 8f-1 (text side): RoBERTa embeddings word[id] + position[cumsum(non-pad)] + token_type[0] -> LayerNorm
- * (HF modeling_roberta.py:56-155; call site preprocessing/preprocess_roberta.py:47-57).  ids: [B,T] int32. */
+ * (HF modeling_roberta.py:56-155; call site preprocessing/preprocess_roberta.py:47-57).  ids: [B,T] int32.
+ * mode (here and in ser_embed_ln_masked / ser_pack_rows / ser_zero_padded_rows): the format of the operand copy, BF16 / FP32X / FP16X. */
 int ser_embed_ln(const int32_t* ids, const float* word_emb, const float* pos_emb, const float* type_emb,
                  const float* ln_g, const float* ln_b, float eps, float* out_f32, void* out_act,
                  int64_t out_plane_stride, int mode, int B, int T, int D, int pad_id, void* stream);

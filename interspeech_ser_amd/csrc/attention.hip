@@ -677,8 +677,8 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     if (gru_const && !args->gate_x && (gate_col < 0 || (gate_col % 2))) return ser_fail(-10, "ser_attention: bad gate_col %d", gate_col);
     if (table && table_T < max_frames) return ser_fail(-7, "ser_attention: bias table built for T=%d < max_frames=%d", table_T, max_frames);
     if (bias2d) {
-        if (table || !key_lens || scale > 0.f || dh > 64 || mode == SER_MODE_FP16 || mode == SER_MODE_FP16X || mode == SER_MODE_FP16Q)
-            return ser_fail(-11, "ser_attention: bias2d needs key_lens, a pre-scaled q (scale <= 0), dh <= 64, no table, bf16 / fp32x");
+        if (table || !key_lens || scale > 0.f || dh > 64 || mode == SER_MODE_FP16 || mode == SER_MODE_FP16Q)
+            return ser_fail(-11, "ser_attention: bias2d needs key_lens, a pre-scaled q (scale <= 0), dh <= 64, no table, bf16 / fp32x / fp16x");
         if (bias2d_ld < max_frames || (bias2d_ld % ABKV))
             return ser_fail(-12, "ser_attention: bias2d_ld=%lld must be a multiple of %d and >= max_frames", (long long)bias2d_ld, ABKV);
     }
@@ -753,6 +753,7 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     }
     if (bias2d)
         return mode == SER_MODE_FP32X ? launch_attention<64, SER_MODE_FP32X, true, false, 4, true>(p, grid, lds, s)
+             : mode == SER_MODE_FP16X ? launch_attention<64, SER_MODE_FP16X, true, false, 4, true>(p, grid, lds, s)
                                       : launch_attention<64, SER_MODE_BF16, true, false, 4, true>(p, grid, lds, s);
 #define SER_ATTN_D(M_) (dhp == 64 ? SER_ATTN(64, M_) : (dhp == 96 ? SER_ATTN(96, M_) : SER_ATTN(128, M_)))
     if (occ) return mode == SER_MODE_FP16 ? SER_ATTN_O(64, SER_MODE_FP16, true) : SER_ATTN_O(64, SER_MODE_BF16, true);

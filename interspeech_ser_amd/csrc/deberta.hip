@@ -62,11 +62,14 @@ extern "C" int ser_embed_ln_masked(const int32_t* ids, const float* word_emb, co
     if (!ids || !word_emb || !ln_g || !ln_b || !key_lens || (!out_f32 && !out_act))
         return ser_fail(-1, "ser_embed_ln_masked: null pointer");
     if (B <= 0 || T <= 0 || D % 4 || D > 2048) return ser_fail(-2, "ser_embed_ln_masked: bad B/T/D");
-    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_embed_ln_masked: bad mode");
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X && mode != SER_MODE_FP16X) return ser_fail(-3, "ser_embed_ln_masked: bad mode");
     const int rows = B * T;
     dim3 grid((rows + 3) / 4), block(256);
     if (mode == SER_MODE_FP32X)
         hipLaunchKernelGGL(embed_ln_masked_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, ids, word_emb, ln_g, ln_b,
+                           eps, key_lens, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, rows);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(embed_ln_masked_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, ids, word_emb, ln_g, ln_b,
                            eps, key_lens, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, rows);
     else
         hipLaunchKernelGGL(embed_ln_masked_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, ids, word_emb, ln_g, ln_b,
@@ -190,6 +193,9 @@ extern "C" int ser_pack_rows(const float* x, int64_t ldx, int B, int T, int D, i
     else if (mode == SER_MODE_BF16)
         hipLaunchKernelGGL(pack_rows_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx, T, D, halo,
                            (unsigned short*)out, ldo, out_plane_stride, total);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(pack_rows_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, ldx, T, D, halo,
+                           (unsigned short*)out, ldo, out_plane_stride, total);
     else return ser_fail(-2, "ser_pack_rows: bad mode %d", mode);
     return ser_check_launch("ser_pack_rows");
 }
@@ -219,6 +225,9 @@ extern "C" int ser_zero_padded_rows(float* x, int64_t ldx, void* act, int64_t ld
                            (unsigned short*)act, lda, plane_stride, key_lens, T, D, total);
     else if (mode == SER_MODE_BF16)
         hipLaunchKernelGGL(zero_padded_rows_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)act, lda, plane_stride, key_lens, T, D, total);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(zero_padded_rows_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, ldx,
                            (unsigned short*)act, lda, plane_stride, key_lens, T, D, total);
     else return ser_fail(-2, "ser_zero_padded_rows: bad mode %d", mode);
     return ser_check_launch("ser_zero_padded_rows");

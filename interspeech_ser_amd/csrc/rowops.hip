@@ -454,11 +454,14 @@ extern "C" int ser_embed_ln(const int32_t* ids, const float* word_emb, const flo
     if (!ids || !word_emb || !pos_emb || !type_emb || !ln_g || !ln_b || (!out_f32 && !out_act))
         return ser_fail(-1, "ser_embed_ln: null pointer");
     if (B <= 0 || T <= 0 || D % 4 || D > 2048) return ser_fail(-2, "ser_embed_ln: bad B/T/D");
-    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X) return ser_fail(-3, "ser_embed_ln: bad mode");
+    if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X && mode != SER_MODE_FP16X) return ser_fail(-3, "ser_embed_ln: bad mode");
     const int rows = B * T;
     dim3 grid((rows + 3) / 4), block(256);
     if (mode == SER_MODE_FP32X)
         hipLaunchKernelGGL(embed_ln_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, ids, word_emb, pos_emb, type_emb,
+                           ln_g, ln_b, eps, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, pad_id, rows);
+    else if (mode == SER_MODE_FP16X)
+        hipLaunchKernelGGL(embed_ln_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, ids, word_emb, pos_emb, type_emb,
                            ln_g, ln_b, eps, out_f32, (unsigned short*)out_act, out_plane_stride, T, D, pad_id, rows);
     else
         hipLaunchKernelGGL(embed_ln_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, ids, word_emb, pos_emb, type_emb,

@@ -538,7 +538,10 @@ def build_text_parser() -> argparse.ArgumentParser:
     p.add_argument("--max_len", type=int, default=80, help="tokens per text (at most 512, the models' position range)")
     p.add_argument("--use_average", type=str, default="n")
     p.add_argument("--batch_size", type=int, default=64)
-    p.add_argument("--mode", type=str, default="fp32x", choices=["fp32x", "bf16"])
+    p.add_argument("--mode", type=str, default="f16x", choices=["f16x", "fp32x", "bf16"],
+                   help="numerics: f16x (default, as in the speech drivers: 3-product split on fp16 hi + lo planes; 5e-6 of the fp32 reference on Gaussian "
+                        "weights, 2-5e-5 under sharp attention at 24 layers; values must stay below 65 504 -- checked per batch), fp32x (the same split on "
+                        "bf16 planes: fp32 range, 2e-5 / 2-3e-4), bf16 (1e-2)")
     p.add_argument("--checkpoint", type=str, default="")
     p.add_argument("--synthetic_weights", action="store_true")
     p.add_argument("--tokenizer_path", type=str, default="", help="local RobertaTokenizer files (default: --roberta_type)")
@@ -554,11 +557,16 @@ class TextExtractor:
         from .engine import build_encoder
         self.enc = build_encoder(geo, state_dict, device, mode)      # RoBERTa (TextEncoder) or DeBERTa-v3 (DebertaEncoder)
         self.tokenize, self.average = tokenize, average
+        self.fp16_planes = mode == "f16x"
 
     def extract(self, texts: Sequence[str]) -> List[torch.Tensor]:
         from .engine import mean_last4
         ids, mask = self.tokenize(list(texts))
         hs = self.enc.forward(ids, mask)
+        if self.fp16_planes:                                         # fp16 operand planes saturate silently: fail the batch instead (speech driver's rule)
+            m = float(hs.max_abs().item())
+            if not m <= _Extractor.F16_LIMIT:
+                raise ValueError(f"hidden states reach {m:.3g}, beyond the fp16 range of --mode f16x: re-run with --mode fp32x")
         sel = mean_last4(hs) if self.average else hs.states[-1]      # .last_hidden_state
         host = sel.to("cpu")
         return [host[hs.frame_offs[b]: hs.frame_offs[b + 1]] for b in range(len(texts))]

@@ -1163,8 +1163,8 @@ class TextEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != FAMILY_ROBERTA:
             raise ValueError("TextEncoder needs a roberta geometry")
-        if mode in ("f16", "f16q", "f16a", "f16x"):
-            raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
+        if mode in ("f16", "f16q", "f16a"):
+            raise ValueError("the text encoders support the bf16, fp32x and f16x numerics modes")
         sd = state_dict
         D = geo.hidden
         self.wemb = self._dev_f32(sd["embeddings.word_embeddings.weight"])
@@ -1275,8 +1275,8 @@ class DebertaEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != "deberta":
             raise ValueError("DebertaEncoder needs a deberta geometry")
-        if mode in ("f16", "f16q", "f16a", "f16x"):
-            raise ValueError("the text encoders support the bf16 and fp32x numerics modes")
+        if mode in ("f16", "f16q", "f16a"):
+            raise ValueError("the text encoders support the bf16, fp32x and f16x numerics modes")
         if geo.head_dim != 64:
             raise ValueError("DeBERTa path: head dim must be 64 (K of the position GEMMs; deberta-v3 base/large have 64)")
         sd = state_dict

@@ -55,7 +55,7 @@ def test_speech_golden_ragged_batch(golden_dir, mode, case):
         for layer in range(ref.shape[0]):
             worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
     print(f"{tag} {mode}: worst rel err {worst:.3e}")
-    assert worst < TOL[mode], worst
+    assert worst < (2e-5 if mode == "f16x" else TOL[mode]), worst
 
 
 @pytest.mark.parametrize("mode", ["f16x", "fp32x", "f16a", "bf16"])
@@ -270,7 +270,7 @@ def test_whisper_golden(golden_dir, mode):
     assert worst < TOL[mode], worst
 
 
-@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32x", "f16x", "bf16"])
 def test_roberta_golden(golden_dir, mode):
     """Next row 8f-1: text encoder states (all 80 rows, padded keys masked) vs the HF fixture."""
     from interspeech_ser_amd import config as C
@@ -293,11 +293,11 @@ def test_roberta_golden(golden_dir, mode):
         for layer in range(ref.shape[0]):
             worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
     print(f"roberta {mode}: worst rel err {worst:.3e}")
-    assert worst < TOL[mode], worst
+    assert worst < (2e-5 if mode == "f16x" else TOL[mode]), worst      # f16x: 22-bit operands (measured 1e-6 .. 4e-6 on the text fixtures)
 
 
 @pytest.mark.parametrize("tag", ["tiny_deberta_d128h2", "tiny_deberta_conv_d128h2"])
-@pytest.mark.parametrize("mode", ["fp32x", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32x", "f16x", "bf16"])
 def test_deberta_golden(golden_dir, mode, tag):
     """DeBERTa-v3 variant of the text side: disentangled attention (log-bucketed relative positions live at 80 tokens with
     16 buckets), both-token mask, padded query rows, vs the HF DebertaV2Model fixture; plus batch-of-one == batched."""
@@ -323,7 +323,7 @@ def test_deberta_golden(golden_dir, mode, tag):
         for layer in range(ref.shape[0]):
             worst = max(worst, rel_err(hs.utterance(j, layer).cpu(), ref[layer]))
     print(f"{tag} {mode}: worst rel err {worst:.3e}")
-    assert worst < TOL[mode], worst
+    assert worst < (2e-5 if mode == "f16x" else TOL[mode]), worst
     one = enc.forward(ids[1:2], mask[1:2])
     torch.cuda.synchronize()
     assert torch.equal(one.utterance(0, geo.num_layers).cpu(), batched[1])

@@ -17,7 +17,7 @@ encs, worst, n = {}, {}, 0
 t_end = time.time() + budget
 while time.time() < t_end:
     fam = ("whisper", "roberta", "deberta")[int(rng.integers(3))]
-    mode = ("fp32x", "bf16", "f16x", "f16", "f16a", "f16q")[int(rng.integers(6 if fam == "whisper" else 2))]
+    mode = ("fp32x", "bf16", "f16x", "f16", "f16a", "f16q")[int(rng.integers(6 if fam == "whisper" else 3))]
     geo = {"whisper": C.TINY_WHISPER, "roberta": C.TINY_ROBERTA, "deberta": C.TINY_DEBERTA}[fam]
     key = (fam, mode)
     if key not in encs:

@@ -1,6 +1,6 @@
 """Text encoders at full depth under sharp attention (GPU box): roberta-large (24 post-LN layers) and deberta-v3-large with the query / key
 projections x F, 4 texts of 80 / 61 / 23 / 5 valid tokens padded to 80, all L + 1 states of every row against the CPU oracle -- the margin of
-the text drivers' default mode (fp32x) at the depth it ships at, like tests/depth_envelope.py for the speech encoders.
+the text drivers' modes (default fp32x; f16x) at the depth they ship at, like tests/depth_envelope.py for the speech encoders.
     python tools/text_depth_check.py [F ...]      (default factors 1 2)"""
 import os, sys
 import torch
@@ -28,7 +28,7 @@ for name in ("roberta-large", "microsoft/deberta-v3-large"):
         with torch.no_grad():
             ref = [oracle(geo, sd, ids[b], mask[b]) for b in range(len(lens))]
         row = []
-        for mode in ("fp32x", "bf16"):
+        for mode in ("f16x", "fp32x", "bf16"):
             enc = build_encoder(geo, sd, "cuda:0", mode)
             hs = enc.forward(ids, mask)
             torch.cuda.synchronize()
