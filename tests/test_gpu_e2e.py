@@ -366,6 +366,51 @@ def test_roberta_driver_files(tmp_path, capsys):
     assert rel_err(got, ref) < 1e-3
 
 
+def test_text_driver_fp16_range_guard(tmp_path, capsys):
+    """The text drivers' default mode is f16x since late round 4 (fp16 hi + lo operand planes, range 65 504): a checkpoint whose
+    states leave that range (a LayerNorm bias of 1e5 in one channel of the last layer) fails its texts with the way out in the message
+    instead of writing clipped features; --mode fp32x extracts it."""
+    import pandas as pd
+    from safetensors.torch import save_file
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_ROBERTA
+    sd = synthetic_state_dict(geo, 5)
+    sd[f"encoder.layer.{geo.num_layers - 1}.output.LayerNorm.bias"][3] += 1.0e5
+    ck = tmp_path / "huge_text.safetensors"
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ck))
+    df = pd.DataFrame({"FileName": ["a.wav", "b.wav"], "transcription": ["hello there", "one two three four"]})
+    csv = tmp_path / "t.csv"
+    df.to_csv(csv, index=False)
+
+    def fake_tokenize(texts):
+        ids = torch.full((len(texts), 16), geo.pad_token_id, dtype=torch.int64)
+        mask = torch.zeros((len(texts), 16), dtype=torch.int64)
+        for i, t in enumerate(texts):
+            toks = [0] + [3 + (len(w) * 7 + j) % (geo.vocab_size - 4) for j, w in enumerate(t.split())] + [2]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return ids, mask
+
+    C._REGISTRY["tiny-text-range"] = geo
+    try:
+        out = tmp_path / "f16x"
+        assert driver.run_roberta(["--roberta_type", "tiny-text-range", "--df_path", str(csv), "--save_path", str(out),
+                                   "--checkpoint", str(ck), "--max_len", "16"], tokenize=fake_tokenize) == 0
+        log = capsys.readouterr().out
+        assert log.count("Failed to process") == 2 and "--mode fp32x" in log, log
+        assert os.listdir(out) == []
+        out2 = tmp_path / "fp32x"
+        assert driver.run_roberta(["--roberta_type", "tiny-text-range", "--df_path", str(csv), "--save_path", str(out2),
+                                   "--checkpoint", str(ck), "--max_len", "16", "--mode", "fp32x"], tokenize=fake_tokenize) == 0
+        log = capsys.readouterr().out
+        assert "Failed to process" not in log and sorted(os.listdir(out2)) == ["a.pt", "b.pt"], log
+        assert float(torch.load(out2 / "a.pt").abs().max()) > 9.0e4
+    finally:
+        C._REGISTRY.pop("tiny-text-range")
+
+
 def test_roberta_driver_with_the_reference_tokenizer_call(tmp_path, capsys):
     """The text driver's DEFAULT tokenizer path -- HF RobertaTokenizer.from_pretrained(<local files>) called like the reference does
     (preprocess_roberta.py:45-54: padding="max_length", truncation=True, max_length=80) -- end to end through ``--tokenizer_path``:
