@@ -11,7 +11,9 @@ DEV = "cuda:0"
 SHAPES = [  # name, M, N, K, gelu, residual, act_out
     ("qkv", 3992, 3104, 1024, 0, 0, 1), ("out", 3992, 1024, 1024, 0, 1, 0), ("fc1", 3992, 4096, 1024, 1, 0, 1),
     ("fc2", 3992, 1024, 4096, 0, 1, 0), ("qkv16", 7984, 3104, 1024, 0, 0, 1), ("fc1_16", 7984, 4096, 1024, 1, 0, 1),
+    ("out16", 7984, 1024, 1024, 0, 1, 0), ("fc2_16", 7984, 1024, 4096, 0, 1, 0),
 ]
+CFGS = tuple(int(c) for c in os.environ.get("SWEEP_CFGS", "1,2,3").split(","))
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 planes = 2 if mode == 2 else 1
 rounds = 7
@@ -23,7 +25,7 @@ for name, M, N, K, gelu, res, act_out in SHAPES:
     of = torch.empty(M, N, device=DEV)
     oa = torch.empty(planes, M, N, dtype=torch.bfloat16, device=DEV)
     res_ms = {}
-    for cfg in (1, 2, 3):
+    for cfg in CFGS:
         g = L.GemmArgs()
         g.A, g.a_plane_stride, g.lda = A.data_ptr(), M * K, K
         g.W, g.w_plane_stride = W.data_ptr(), N * K
