@@ -844,7 +844,12 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         // Measured on the step (two A/B pairs, one box): the packed QKV projection on it f16a 1 110 / 1 114 -> 1 134 / 1 130 utt/s; FC1 too
         // (its GELU epilogue on 128 accumulators + 64 spilled bias / column-sum registers) gives the gain back: fp32x 848 -> 846.
         // Hence only launches without an activation take it.
-        if (x32_sq_min > 0 && a->N >= 256 && t256sq >= x32_sq_min && a->act == SER_ACT_NONE) return launch_cfg<4, 2, 4, 8, 32, 2, false, true>(a, s);
+        // ... and only grids whose last round of 256 blocks is mostly full (round 4): WavLM-large's packed projection has 384 such tiles = 1.5 rounds
+        // (efficiency 0.75) and is 0.5 % faster on the f16x step as 768 tiles of 256x128 = 3 full rounds (XLS-R-2B at 8 x 10 s, 368 tiles: + 0.2 %), while
+        // HuBERT-xlarge's 480 (0.94) and Whisper's 705 (0.92) lose 2.7 % / 4.7 % of their steps without the square tile (same-box pairs, experiments build).
+        const long sq_rounds = (t256sq + 255) / 256;
+        const bool sq_full = t256sq * 100 >= sq_rounds * 256 * 85;
+        if (x32_sq_min > 0 && a->N >= 256 && t256sq >= x32_sq_min && sq_full && a->act == SER_ACT_NONE) return launch_cfg<4, 2, 4, 8, 32, 2, false, true>(a, s);
         if (x32_256_min > 0 && a->N >= 128 && t256x128 >= x32_256_min) return launch_cfg<4, 2, 4, 4, 32, 3, false, true>(a, s);
         return launch_cfg<4, 2, 2, 4, 64, 2, false, true>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
     }
