@@ -54,7 +54,7 @@ def _speech_config(ssl_type, batch, seed, oracle_utts=(0,)):
     from interspeech_ser_amd.weights import synthetic_state_dict
     from oracle import ssl_oracle as O
     geo = C.geometry_for(ssl_type)
-    sd = synthetic_state_dict(geo, 0)
+    sd = synthetic_state_dict(geo, 0, fast=True)             # torch's generator: seconds instead of half a minute for 2 B parameters
     num_samples = 160000
     waves = synth_clips(batch, num_samples, seed)
     lengths = [num_samples] * batch
@@ -136,7 +136,7 @@ def test_config3_whisper_large_v3_16x30s():
     from interspeech_ser_amd.weights import synthetic_state_dict
     from oracle import ssl_oracle as O
     geo = C.geometry_for("openai/whisper-large-v3")
-    sd = synthetic_state_dict(geo, 0)
+    sd = synthetic_state_dict(geo, 0, fast=True)             # torch's generator: seconds instead of half a minute for 2 B parameters
     secs = [30.0, 7.3, 12.0, 30.0, 3.0, 22.5, 9.9, 30.0, 15.0, 4.2, 28.0, 30.0, 11.1, 6.0, 19.0, 30.0]
     g = torch.Generator().manual_seed(1236)
     waves = [(0.1 * torch.randn(int(s * 16000), generator=g)).numpy() for s in secs]

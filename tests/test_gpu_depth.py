@@ -19,8 +19,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GATE = 1e-3
-CASES = [("wavlm", "sharp2"), ("wavlm", "outliers"), ("wavlm", "rowmean"), ("wavlm", "lora"),
-         ("hubert", "sharp2")]           # (hubert lora / rowmean / outliers, XLS-R-2B: profiles/r04_depth_envelope*.txt; the suite's time budget)
+CASES = [("wavlm", "sharp2"), ("wavlm", "outliers"), ("wavlm", "lora"),
+         ("hubert", "sharp2")]           # (wavlm rowmean, hubert lora / rowmean / outliers, XLS-R-2B: profiles/r04_depth_envelope*.txt; the suite's time
+                                         # budget -- the CPU oracle's share doubles on a slow box: 581 s / 839 s for the same suite on two boxes)
 
 
 @pytest.mark.parametrize("model,kind", CASES)
