@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 12
+#define SER_ABI_VERSION 13
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -53,6 +53,22 @@ extern "C" {
                             * single-product rounding is amplified (reference arithmetic is fp32: preprocess_speech.py:50,66) */
 #define SER_MODE_FP16Q 5   /* ser_attention only: q and k are FP16X column blocks (3-product S = K Q^T), v is read from plane 0 and
                             * P V runs single fp16 products; the output is a single-plane FP16 tensor */
+
+#define SER_MODE_FP16M 6   /* round 5, the "f16m" numerics mode: fp16 main product + block-scaled 8-bit cross terms on gfx950's
+                            * v_mfma_scale_f32_16x16x128_f8f6f4 -- x W^T ~= x_hi w_hi + x_lo w_8 + x_8 w_lo, i.e. 1 + 1/2 + 1/2 = 2 fp16 product-
+                            * equivalents per algorithmic FLOP instead of FP16X's 3 (the scaled e4m3 instruction runs at twice the fp16 rate).
+                            * An FP16M tensor has
+                            *   plane 0 (at base):                fp16 hi = fp16(x), [rows][ld], exactly the FP16 copy;
+                            *   plane 1 (at base + plane_stride): the CROSS-TERM plane, same pitch in bytes: for every row and every 64-column tile t,
+                            *       the 128 bytes at byte offset 2 * (row * ld + 64 t) hold [P: 64 e4m3 bytes, columns 64t .. 64t+63][Q: 64 e4m3 bytes];
+                            *       activations: P = x - hi (the fp16 rounding residual), Q = x;   weights: P = w, Q = w - fp16(w);
+                            *   scales (their own pointer): uint32 [ld / 64][scale_ld], word (t, row) = four E8M0 codes (value 2^(c - 127)), one per
+                            *       32 consecutive elements: [P cols 0-31, P cols 32-63, Q cols 0-31, Q cols 32-63] of tile t -- the OCP MX block format,
+                            *       the smallest power of two that brings the block's largest magnitude to <= 448.
+                            * ser_gemm accumulates, per 64-deep K tile, two fp16 MFMA k-steps (hi x hi) and ONE scaled e4m3 MFMA whose 128-long K is
+                            * [P | Q] of both operands: P_a P_w + Q_a Q_w = x_lo w_8 + x_8 w_lo.  The cross terms carry 2^-11 of the result, so their
+                            * 4-bit significands leave an operand error of ~2^-15 (oracle/numerics_whatif_f16m.py).  Range: fp16's (saturation at
+                            * +-65504, reported through range_flag).  Reference arithmetic is fp32 end to end (preprocess_speech.py:50,66). */
 
 #define SER_ACT_NONE 0
 #define SER_ACT_GELU 1     /* exact erf GELU (ACT2FN["gelu"]) */
@@ -161,6 +177,17 @@ typedef struct ser_gemm_args {
     float*         mean_out;       /* [M] absolute row mean of the A rows (consumer), or NULL */
     float*         lnstat_out;     /* [M][2] (row mean relative to ln_shift, 1/sqrt(var + eps)) the consumer derived from ln_stats_in, or
                                     * NULL: what ser_attention's in-kernel WavLM gate (ser_attention_args.gate_x) applies to the same rows */
+    /* SER_MODE_FP16M operands (ABI 13): block scales of A (row index m; needs a_rowoff == NULL, kc == 0, groups == 1) and of W (row index n),
+     * and -- with out_mode == SER_MODE_FP16M -- of the out_act copy (row index out_row(m), tile index (output column) / 64; the first output
+     * column of the launch must be a multiple of 64).  *_scale_ld = words between consecutive 64-column tiles. */
+    const uint32_t* a_scale;  int64_t a_scale_ld;
+    const uint32_t* w_scale;  int64_t w_scale_ld;
+    uint32_t*       out_scale; int64_t out_scale_ld;
+    /* fp16 range guard (ABI 13): when not NULL, the launch ORs 1 into *range_flag if any value it rounds to an fp16 operand plane
+     * (out_act in the FP16 / FP16X / FP16M formats) exceeds 65504 in magnitude BEFORE the saturating conversion -- the host reads the
+     * word back with the batch's features and fails that batch's files instead of writing clipped ones (preprocess_speech.py:46,72-73:
+     * a bad file is a printed failure, never silent garbage). */
+    uint32_t*       range_flag;
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
 
@@ -278,6 +305,12 @@ int ser_mean4(const float* s0, const float* s1, const float* s2, const float* s3
 /* weights: fp32 -> bf16 hi (+ lo) planes, done once at load. */
 int ser_split_bf16(const float* x, void* out, int64_t plane_stride, int mode, int64_t n, void* stream);
 
+/* fp32 [rows][ldx] -> a SER_MODE_FP16M tensor (see the mode's comment): hi plane at out, cross-term plane at out + plane_stride (elements),
+ * scale words at scales[t * scale_ld + row].  cols % 64 == 0, ldo % 64 == 0.  is_weight selects the plane roles (weights: P = w, Q = w - hi;
+ * activations: P = x - hi, Q = x).  Used at load for the weights (HF modeling_wavlm.py:133-136,288-294 Linear weights) and by the kernel tests. */
+int ser_pack_f16m(const float* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int64_t plane_stride,
+                  uint32_t* scales, int64_t scale_ld, int is_weight, uint32_t* range_flag, void* stream);
+
 /* Row-index tables of a packed ragged batch, built on the device (no per-batch host tables to upload):
  *   out[m] = (base[b] + step * (m - row_offs[b])) * mult / div      for row_offs[b] <= m < row_offs[b+1]
  * row_offs: [B+1] int32 first output row of every utterance; base: [B] int64.  This is the implicit-conv row offset
@@ -327,7 +360,10 @@ typedef struct ser_layernorm_args {
 typedef struct ser_row_center_args {
     const float* x; int64_t ldx; void* out_act; int64_t ldo_act; int64_t out_plane_stride;
     float* stats; float* shift; int32_t stat_groups, mode, rows, D;
+    uint32_t* out_scale; int64_t out_scale_ld;      /* mode == SER_MODE_FP16M: block scales of the copy (ABI 13) */
+    uint32_t* range_flag;                           /* fp16 range guard, may be NULL (see ser_gemm_args.range_flag) */
 } ser_row_center_args;
+int ser_row_center_v(const ser_row_center_args* args, void* stream);
 
 typedef struct ser_logmel_args {
     const float* wav; const int64_t* sample_offs; const float* mel; float* out; void* work; int32_t B, n_mels;

@@ -20,11 +20,12 @@ MODE_FP32X = 2
 MODE_FP16 = 3
 MODE_FP16X = 4
 MODE_FP16Q = 5
+MODE_FP16M = 6
 ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
 WS_WAVE_FRAMES = 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -48,6 +49,8 @@ class GemmArgs(C.Structure):
         ("col_scale", c_float), ("col_scale_end", C.c_int32),
         ("shift_in", c_void_p), ("shift_out", c_void_p), ("shift_const", c_float), ("out_mode", C.c_int32),
         ("ln_shift", c_void_p), ("mean_out", c_void_p), ("lnstat_out", c_void_p),
+        ("a_scale", c_void_p), ("a_scale_ld", c_i64), ("w_scale", c_void_p), ("w_scale_ld", c_i64),
+        ("out_scale", c_void_p), ("out_scale_ld", c_i64), ("range_flag", c_void_p),
     ]
 
 
@@ -94,6 +97,7 @@ class RowCenterArgs(C.Structure):
         ("x", c_void_p), ("ldx", c_i64), ("out_act", c_void_p), ("ldo_act", c_i64), ("out_plane_stride", c_i64),
         ("stats", c_void_p), ("shift", c_void_p),
         ("stat_groups", C.c_int32), ("mode", C.c_int32), ("rows", C.c_int32), ("D", C.c_int32),
+        ("out_scale", c_void_p), ("out_scale_ld", c_i64), ("range_flag", c_void_p),
     ]
 
 
@@ -136,6 +140,8 @@ _SIGNATURES = {
     "ser_layernorm": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_i64, c_void_p, c_i64,
                               c_i64, c_int, c_int, c_int, c_void_p]),
     "ser_row_center": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ser_row_center_v": (c_int, [c_void_p, c_void_p]),
+    "ser_pack_f16m": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "ser_wavlm_bias_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ser_wavlm_gate": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                c_int, c_void_p]),

@@ -53,9 +53,7 @@ extern "C" int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void*
                 break;
             }
             case SER_OP_ROW_CENTER: {
-                const ser_row_center_args& a = c.u.row_center;
-                rc = ser_row_center(a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride, a.stats, a.stat_groups, a.shift,
-                                    a.mode, a.rows, a.D, stream);
+                rc = ser_row_center_v(&c.u.row_center, stream);
                 break;
             }
             case SER_OP_LOGMEL: {

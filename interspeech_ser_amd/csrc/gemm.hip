@@ -21,6 +21,8 @@
 //     K tiles stay in flight across the barrier (a __syncthreads() would drain them), one barrier
 //     per K tile, s_setprio around the MFMA cluster.
 //   * FP32X mode runs the same loop over 3 K-segments (hi*hi, lo*hi, hi*lo) into one accumulator.
+//   * FP16M mode (round 5): the ring carries TWO units per 64-deep K tile -- the fp16 hi planes (two f16 MFMA k-steps) and the e4m3 cross-term
+//     planes + their block scales (ONE v_mfma_scale_f32_16x16x128_f8f6f4 per fragment pair): 2 product-equivalents instead of FP16X's 3.
 //   * blockIdx.x -> tile through a bijective XCD swizzle so each of the 8 L2s sees a contiguous run
 //     of tiles that share activation panels.
 #include "ser_common.h"
@@ -30,6 +32,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <atomic>
+#include <type_traits>
 #ifdef SER_GEMM_DBG
 // diagnostic build only (tools/gemm_clock.py): wave 0 of every block stamps s_memtime / s_memrealtime around its K loop
 extern "C" { void* ser_gemm_dbg_ptr = nullptr; }
@@ -48,11 +51,33 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N < 0, "add a case");
+}
+
+// acc += (block-scaled e4m3 A) x (block-scaled e4m3 B), 16 x 16 x 128.  Issued from inline asm with the accumulator TIED: hipcc (ROCm 7.2) gives the
+// builtin's result a fresh register quad (its destination is early-clobber, never coalesced with the C input), so the 128 accumulators of the
+// 256x256 tile rotate through the file and 50 - 120 registers spill, some inside the K loop.  Hazards the compiler no longer sees: every call site
+// sits behind an s_barrier + LDS waits after the last writer of its operands, consecutive calls target different accumulators, and the K loop ends
+// in mfma_scale_drain() before anything else reads the accumulators.
+#ifndef SER_MX_ASM
+#define SER_MX_ASM 1
+#endif
+__device__ __forceinline__ void mfma_scale8(f32x4& acc, const i32x8& a, const i32x8& b, int sa, int sb) {
+#if SER_MX_ASM
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+#else
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, sa, 0, sb);
+#endif
+}
+__device__ __forceinline__ void mfma_scale_drain() {
+#if SER_MX_ASM
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");          // > the 8 passes of the last scaled MFMA
+#endif
 }
 
 // WM x WN waves, each TM x TN MFMA tiles of 16x16; BK = K tile; ST = ring stages.
@@ -70,8 +95,13 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     // FP32X: both planes (hi, lo) of the A and W tiles of a K tile sit in one stage, fetched ONCE, and every
     // fragment pair feeds 3 MFMAs (hi*hi, lo*hi, hi*lo): 2x the L2->LDS bytes of bf16 for 3x the products,
     // instead of three full passes over K
-    constexpr int NPL = mode_traits<MODE>::planes;               // FP32X (bf16 hi/lo) and FP16X (fp16 hi/lo)
+    // FP16M: a stage holds ONE unit of a K tile -- its fp16 hi planes (even units) or its e4m3 cross-term planes (odd units), both
+    // [rows][128 bytes] images with the same swizzle -- so the ring is the single-plane one walked twice per K tile
+    constexpr bool M16 = (MODE == SER_MODE_FP16M);
+    constexpr int NPL = M16 ? 1 : mode_traits<MODE>::planes;     // FP32X (bf16 hi/lo) and FP16X (fp16 hi/lo)
     constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = NPL * (A_BYTES + W_BYTES);
+    static_assert(!M16 || (BK == 64 && !LNEPI && (BM + BN) % 64 == 0), "FP16M: 64-deep K tiles, dense epilogue");
+    constexpr int SCW = BM + BN;                  // FP16M: scale words per unit (one per A row and W row of the tile)
     constexpr int LA = BM / RPP / NW, LW = BN / RPP / NW;       // DMA pieces per wave per K tile
     constexpr int LPT = NPL * (LA + LW);
     constexpr int KS = BK / 32;                   // MFMA k-steps per K tile
@@ -127,13 +157,32 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     }
 
     const int nk = p.K / BK;
-    const int total = nk;
+    const int total = M16 ? 2 * nk : nk;          // FP16M: two ring units per K tile
     const int tpc = p.kc ? p.kc / BK : 0x7fffffff;                                // K tiles per conv chunk
 
+    // FP16M: block scales of the tile's rows, one word per (row, K tile), fetched with the cross-term unit: wave w brings 64 of the
+    // BM + BN words (A rows first), 4 bytes per lane; with more waves than 64-row chunks the surplus waves repeat a chunk (same bytes,
+    // same place), so every wave issues the same number of DMAs and the counted waits stay uniform
+    unsigned char* const scl = (unsigned char*)(lds + ST * STAGE + (LNEPI ? 0 : BM * 8));     // [ST][SCW] words, behind the row statistics
+    const uint32_t* sc_src = nullptr;
+    int64_t sc_step = 0;
+    const int sc_chunk = M16 ? (wave % (SCW / 64)) : 0;
+    if constexpr (M16) {
+        const int r = sc_chunk * 64 + lane;
+        if (r < BM) { int m = m0 + r; m = m < p.M ? m : p.M - 1; sc_src = p.a_scale + m; sc_step = p.a_scale_ld; }
+        else { int n = n0 + r - BM; n = n < p.N ? n : p.N - 1; sc_src = p.w_scale + n; sc_step = p.w_scale_ld; }
+    }
     int i_kk = 0, i_cc = 0, i_cj = 0, i_stage = 0;                               // issue-side scalar state
     auto issue = [&]() {
-        const int64_t koffA = (int64_t)i_cj * p.ldj + (int64_t)i_cc * BK;
-        const int64_t koffW = (int64_t)i_kk * BK;
+        int64_t koffA = (int64_t)i_cj * p.ldj + (int64_t)i_cc * BK;
+        int64_t koffW = (int64_t)i_kk * BK;
+        if constexpr (M16) {                                     // unit i_kk: K tile i_kk / 2, plane i_kk & 1 (same byte offsets in both planes)
+            koffA = (int64_t)(i_kk >> 1) * BK + (i_kk & 1) * p.a_plane_stride;
+            koffW = (int64_t)(i_kk >> 1) * BK + (i_kk & 1) * p.w_plane_stride;
+            if (i_kk & 1)
+                __builtin_amdgcn_global_load_lds((gptr_t)(sc_src + (int64_t)(i_kk >> 1) * sc_step),
+                                                 (lptr_t)(scl + (i_stage * SCW + sc_chunk * 64) * 4), 4, 0, 0);
+        }
         char* dstA = lds + i_stage * STAGE + wave * 1024;        // stage = [A hi][A lo][W hi][W lo]
         char* dstW = dstA + NPL * A_BYTES;
 #pragma unroll
@@ -175,30 +224,32 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr int CPL = TN * 4;
     const int ncol0 = n0 + wn * (TN * 16) + fq * 4;                   // column of acc[0][.][0] within the group
     const int64_t gcol = (int64_t)g * p.c_group_stride + ncol0;       // in the output matrices
-    float bias[CPL];
+    // per-column epilogue constants (bias, deferred-LayerNorm column sums): 2 * TN * 4 registers.  The FP16M tiles request them AFTER the
+    // K loop -- beside the 128 accumulators and the 64 + 8 registers of a cross-term phase they would spill (86 - 116 registers, some
+    // inside the loop, on the 256x256 tile); everybody else keeps them across the loop (the loads fly beside the first DMA tiles)
+    float bias[CPL], csum[CPL];
+    auto load_cols = [&]() {
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) bias[j] = 0.f;
-    if (p.bias) {
+        for (int j = 0; j < CPL; ++j) { bias[j] = 0.f; csum[j] = 0.f; }
+        if (p.bias) {
 #pragma unroll
-        for (int j4 = 0; j4 < TN; ++j4)
-            if (ncol0 + j4 * 16 < p.N) {
-                const f32x4 b = *(const f32x4*)(p.bias + (int64_t)g * p.N + ncol0 + j4 * 16);
-                bias[j4 * 4 + 0] = b[0]; bias[j4 * 4 + 1] = b[1]; bias[j4 * 4 + 2] = b[2]; bias[j4 * 4 + 3] = b[3];
-            }
-    }
-
-    // deferred LayerNorm (see ser_hip.h): per-column sum of the gamma-folded weights
-    float csum[CPL];
+            for (int j4 = 0; j4 < TN; ++j4)
+                if (ncol0 + j4 * 16 < p.N) {
+                    const f32x4 b = *(const f32x4*)(p.bias + (int64_t)g * p.N + ncol0 + j4 * 16);
+                    bias[j4 * 4 + 0] = b[0]; bias[j4 * 4 + 1] = b[1]; bias[j4 * 4 + 2] = b[2]; bias[j4 * 4 + 3] = b[3];
+                }
+        }
+        // deferred LayerNorm (see ser_hip.h): per-column sum of the gamma-folded weights
+        if (p.ln_colsum) {
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) csum[j] = 0.f;
-    if (p.ln_colsum) {
-#pragma unroll
-        for (int j4 = 0; j4 < TN; ++j4)
-            if (ncol0 + j4 * 16 < p.N) {
-                const f32x4 b = *(const f32x4*)(p.ln_colsum + ncol0 + j4 * 16);
-                csum[j4 * 4 + 0] = b[0]; csum[j4 * 4 + 1] = b[1]; csum[j4 * 4 + 2] = b[2]; csum[j4 * 4 + 3] = b[3];
-            }
-    }
+            for (int j4 = 0; j4 < TN; ++j4)
+                if (ncol0 + j4 * 16 < p.N) {
+                    const f32x4 b = *(const f32x4*)(p.ln_colsum + ncol0 + j4 * 16);
+                    csum[j4 * 4 + 0] = b[0]; csum[j4 * 4 + 1] = b[1]; csum[j4 * 4 + 2] = b[2]; csum[j4 * 4 + 3] = b[3];
+                }
+        }
+    };
+    if constexpr (!M16) load_cols();
 
 #pragma unroll
     for (int t = 0; t < ST - 1; ++t)
@@ -250,7 +301,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int PP_BIT = NPL == 2 ? (LNEPI ? 16 : 8) : (LNEPI ? 4 : (TM * TN >= 32 ? 1 : 2));
-    constexpr bool PP = (SER_GEMM_PP & PP_BIT) && NW == 8 && (KS == 2 || NPL == 2);
+    constexpr bool PP = !M16 && (SER_GEMM_PP & PP_BIT) && NW == 8 && (KS == 2 || NPL == 2);
     constexpr int PH = (NPL == 1 && TM * TN >= 32) ? KS : 1;          // read phases per K tile (FP32X: 12 fragments + 24 MFMAs per k-step, one phase)
     constexpr int SPP = KS / PH;                                      // k-steps per phase
     // FP32X tiles with 64x128 wave tiles (the LayerNorm tile: one k-step per 32-deep K tile, 24 fragments, 96 MFMAs): the two read
@@ -368,8 +419,147 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
         }
     }
+
+    // ---- FP16M: per 64-deep K tile one H unit (fp16 hi planes: the two f16 k-steps of the single-plane loop) and one E unit (e4m3
+    // cross-term planes: each lane's 32 operand bytes are chunks fq and fq + 4 of its row -- the addresses of the two k-steps -- and
+    // its scale byte is byte fq of the row's scale word; the instruction pairs chunk c of the weights with chunk c of the activations
+    // and applies the scale of lane group b to chunks 2b, 2b + 1: [P cols 0-31, P cols 32-63, Q cols 0-31, Q cols 32-63], tools/mxprobe.hip).
+    // Same ring, same ping-pong phases as the single-plane tiles; an E phase of the 256x128 / 128x128 tiles is TM x TN = 16 scaled MFMAs = the
+    // matrix-pipe time of the 32 f16 MFMAs of its H phase.
+    if constexpr (M16) {
+        constexpr int LPTH = LPT, LPTE = LPT + 1;
+        constexpr bool PPM = (NW == 8);
+        constexpr int PHM = (TM * TN >= 32) ? 2 : 1;                  // phases per unit (256x256: two, like its bf16 form)
+        constexpr int SPM = KS / PHM;                                 // H unit: k-steps per phase
+        // E unit: phases and activation row fragments per phase
+        constexpr int PHE = PHM;
+        constexpr int TMP = TM / PHE;
+        // unit kt has landed once at most the youngest unit (kt + ST - 1 ... only ST = 2, 3 exist) is still in flight
+        auto wait_landed = [&](bool more, int young) {
+            if (!more || ST == 2) wait_vmcnt<0>();
+            else if (young & 1) wait_vmcnt<LPTE * (ST - 2)>();
+            else wait_vmcnt<LPTH * (ST - 2)>();
+        };
+        auto h_phase_reads = [&](const char* sb, int ph, auto& af, auto& wf) {
+#pragma unroll
+            for (int u = 0; u < SPM; ++u) {
+#pragma unroll
+                for (int x = 0; x < TM; ++x) af[u][x] = *(const bf16x8*)(sb + offA[ph * SPM + u] + x * 16 * ROWB);
+#pragma unroll
+                for (int x = 0; x < TN; ++x) wf[u][x] = *(const bf16x8*)(sb + offW[ph * SPM + u] + x * 16 * ROWB);
+            }
+        };
+        auto h_phase_mfma = [&](auto& af, auto& wf) {
+#pragma unroll
+            for (int u = 0; u < SPM; ++u)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = mfma16<SER_MODE_FP16>(wf[u][ni], af[u][mi], acc[ni][mi]);
+        };
+        auto e_phase_reads = [&](const char* sb, const unsigned char* scb, int ph, auto& a8, auto& w8, auto& sa, auto& sw) {
+#pragma unroll
+            for (int x = 0; x < TMP; ++x) {
+                const int mi = ph * TMP + x;
+                const u32x4 c0 = *(const u32x4*)(sb + offA[0] + mi * 16 * ROWB), c1 = *(const u32x4*)(sb + offA[1] + mi * 16 * ROWB);
+                a8[x] = (i32x8){(int)c0[0], (int)c0[1], (int)c0[2], (int)c0[3], (int)c1[0], (int)c1[1], (int)c1[2], (int)c1[3]};
+                sa[x] = scb[(wm * TM * 16 + mi * 16 + frow) * 4 + fq];
+            }
+#pragma unroll
+            for (int x = 0; x < TN; ++x) {
+                const u32x4 c0 = *(const u32x4*)(sb + offW[0] + x * 16 * ROWB), c1 = *(const u32x4*)(sb + offW[1] + x * 16 * ROWB);
+                w8[x] = (i32x8){(int)c0[0], (int)c0[1], (int)c0[2], (int)c0[3], (int)c1[0], (int)c1[1], (int)c1[2], (int)c1[3]};
+                sw[x] = scb[(BM + wn * TN * 16 + x * 16 + frow) * 4 + fq];
+            }
+        };
+        auto e_phase_mfma = [&](int ph, auto& a8, auto& w8, auto& sa, auto& sw) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int x = 0; x < TMP; ++x)
+                    mfma_scale8(acc[ni][ph * TMP + x], w8[ni], a8[x], sw[ni], sa[x]);
+        };
+        // (the two kinds of unit are separate instantiations of one lambda, called alternately: with a run-time parity branch around the
+        // phase bodies hipcc kept both fragment sets live and spilled 160 - 540 registers)
+        if constexpr (PPM) {
+            const int late = wave >> 2;
+            wait_landed(total >= ST - 1, ST - 2);                         // units 0 .. ST-2 are in flight; unit 0 has landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (late) __builtin_amdgcn_s_barrier();
+            int stage = 0;
+            auto unit = [&](int kt, auto etag) {
+                constexpr bool EU = decltype(etag)::value;
+                const bool more = kt + ST - 1 < total;
+                if (more) issue();
+                const char* sb = lds + stage * STAGE;
+                const unsigned char* scb = scl + stage * SCW * 4;
+                stage = (stage + 1 == ST) ? 0 : stage + 1;
+                const bool last = kt + 1 == total;
+                constexpr int NPH = EU ? PHE : PHM;
+#pragma unroll
+                for (int ph = 0; ph < NPH; ++ph) {
+                    bf16x8 af[EU ? 1 : SPM][EU ? 1 : TM], wf[EU ? 1 : SPM][EU ? 1 : TN];
+                    i32x8 a8[EU ? TMP : 1], w8[EU ? TN : 1];
+                    int sa[EU ? TMP : 1], sw[EU ? TN : 1];
+                    if constexpr (!EU) h_phase_reads(sb, ph, af, wf);
+                    else e_phase_reads(sb, scb, ph, a8, w8, sa, sw);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ph == NPH - 1 && late) wait_landed(more, kt + ST - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+                    if constexpr (!EU) h_phase_mfma(af, wf);
+                    else e_phase_mfma(ph, a8, w8, sa, sw);
+                    __builtin_amdgcn_s_setprio(0);
+                    if (ph == NPH - 1 && !late) wait_landed(more, kt + ST - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ph == NPH - 1 && last && late)) __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            for (int kt = 0; kt < total; kt += 2) {
+                unit(kt, std::false_type{});
+                unit(kt + 1, std::true_type{});
+            }
+        } else {
+            int stage = 0;
+            auto unit = [&](int kt, auto etag) {
+                constexpr bool EU = decltype(etag)::value;
+                wait_landed(kt + (ST - 2) < total, kt + ST - 2);
+                __builtin_amdgcn_s_barrier();
+                if (kt + ST - 1 < total) issue();
+                const char* sb = lds + stage * STAGE;
+                const unsigned char* scb = scl + stage * SCW * 4;
+                stage = (stage + 1 == ST) ? 0 : stage + 1;
+#pragma unroll
+                for (int ph = 0; ph < (EU ? PHE : PHM); ++ph) {
+                    if constexpr (!EU) {
+                        bf16x8 af[SPM][TM], wf[SPM][TN];
+                        h_phase_reads(sb, ph, af, wf);
+                        __builtin_amdgcn_s_setprio(1);
+                        h_phase_mfma(af, wf);
+                        __builtin_amdgcn_s_setprio(0);
+                    } else {
+                        i32x8 a8[TMP], w8[TN];
+                        int sa[TMP], sw[TN];
+                        e_phase_reads(sb, scb, ph, a8, w8, sa, sw);
+                        __builtin_amdgcn_s_setprio(1);
+                        e_phase_mfma(ph, a8, w8, sa, sw);
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                }
+            };
+            for (int kt = 0; kt < total; kt += 2) {
+                unit(kt, std::false_type{});
+                unit(kt + 1, std::true_type{});
+            }
+        }
+    }
+    if constexpr (M16) mfma_scale_drain();
     int c_stage = 0;
-    for (int kt = 0; kt < (PP ? 0 : total); ++kt) {
+    for (int kt = 0; kt < ((PP || M16) ? 0 : total); ++kt) {
         // tile kt has landed once at most (ST-2) younger tiles are still in flight
         if (kt + (ST - 2) < total) wait_vmcnt<LPT * (ST - 2)>();
         else wait_vmcnt<0>();
@@ -448,7 +638,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         }
     }
 #endif
+    if constexpr (M16) load_cols();
     // ---- epilogue: lane owns row m (per mi) and TN*4 consecutive columns ----------------------
+    float ramax = 0.f;                            // largest |value| this lane rounded to an fp16 operand plane (range guard)
     if constexpr (LNEPI) {
         // LayerNorm over the full row (N <= BN, one N tile) + GELU, two-pass statistics.
         // Row partials cross the WN waves of a block row through LDS (the ring is idle now).
@@ -530,6 +722,12 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     const int c8 = ni * 16 + ((fq & 1) ? 12 : 0);     // after the swap this lane holds columns c8..c8+7
                     store_act8_swap<MODE>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + c8, p.out_plane_stride,
                                           ncol0 + c8 < p.N, v);
+                    if constexpr (mode_traits<MODE>::f16) {           // fp16 range guard (ser_hip.h range_flag)
+                        if (p.range_flag) {
+#pragma unroll
+                            for (int r = 0; r < 8; r += 2) ramax = fmaxf(ramax, fmaxf(fabsf(v[r]), fabsf(v[r + 1])));
+                        }
+                    }
                 }
             }
         }
@@ -587,6 +785,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             const float cshift = cs[mi];
             if (p.shift_out && nt == 0 && g == 0 && wn == 0 && fq == 0) p.shift_out[m] = cshift;
             float st1 = 0.f, st2 = 0.f;
+            unsigned mcode[2] = {0u, 0u};                             // FP16M out copy: (P, Q) codes of the two blocks of a 64-column tile
 #pragma unroll
             for (int ni = 0; ni < TN; ni += 2) {                      // fragment column blocks ni, ni+1: 4 + 4 columns
                 const bool ok0 = ncol0 + ni * 16 < p.N, ok1 = ncol0 + ni * 16 + 16 < p.N;
@@ -631,8 +830,42 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 }
                 if (p.out_act) {
                     const int c8 = ni * 16 + ((fq & 1) ? 12 : 0);     // after the swap this lane holds columns c8..c8+7
-                    store_act8_swap<OM>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + c8, p.out_plane_stride,
-                                        ncol0 + c8 < p.N, v);
+                    if constexpr (OM == SER_MODE_FP16M) {
+                        // hi plane = the fp16 copy; cross-term plane: P = v - hi, Q = v as e4m3 with one power-of-two scale per 32 columns
+                        // (this fragment pair = one block: the four lanes of the row hold 8 of its columns each)
+                        store_act8_swap<SER_MODE_FP16>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + c8, 0, ncol0 + c8 < p.N, v);
+                        float lo[8], ax = 0.f, al = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 8; r += 2) {
+                            const unsigned h2 = pack_h2(v[r], v[r + 1]);
+                            lo[r] = v[r] - h2f((unsigned short)(h2 & 0xffffu));
+                            lo[r + 1] = v[r + 1] - h2f((unsigned short)(h2 >> 16));
+                            ax = fmaxf(ax, fmaxf(fabsf(v[r]), fabsf(v[r + 1])));
+                            al = fmaxf(al, fmaxf(fabsf(lo[r]), fabsf(lo[r + 1])));
+                        }
+                        ramax = fmaxf(ramax, ax);
+                        ax = max_rowquad(ax); al = max_rowquad(al);
+                        const unsigned cx = mx_code(ax), cl = mx_code(al);
+                        const float ix = mx_inv(cx), il = mx_inv(cl);
+                        unsigned q4[4] = {mx_pack4(lo[0] * il, lo[1] * il, lo[2] * il, lo[3] * il), mx_pack4(lo[4] * il, lo[5] * il, lo[6] * il, lo[7] * il),
+                                          mx_pack4(v[0] * ix, v[1] * ix, v[2] * ix, v[3] * ix), mx_pack4(v[4] * ix, v[5] * ix, v[6] * ix, v[7] * ix)};
+                        transpose_rowquad(q4);        // lane group fq now holds 16 consecutive bytes: P cols 0-15 | P 16-31 | Q 0-15 | Q 16-31 of the block
+                        const int64_t bcol = gcol - fq * 4 + ni * 16;                    // the block's first output column
+                        unsigned char* seg = (unsigned char*)((unsigned short*)p.out_act + p.out_plane_stride) + (orow * p.ldo_act + (bcol & ~(int64_t)63)) * 2;
+                        if (ok0) *(u32x4*)(seg + (fq >> 1) * 64 + (bcol & 63) + (fq & 1) * 16) = (u32x4){q4[0], q4[1], q4[2], q4[3]};
+                        mcode[(ni >> 1) & 1] = cl | (cx << 16);
+                        if (((ni >> 1) & 1) && fq == 0 && ok0)                            // second block of a 64-column tile: its scale word
+                            p.out_scale[(bcol >> 6) * p.out_scale_ld + orow] = (mcode[0] & 0xffu) | ((mcode[1] & 0xffu) << 8) | (mcode[0] & 0xff0000u) | ((mcode[1] & 0xff0000u) << 8);
+                    } else {
+                        store_act8_swap<OM>((unsigned short*)p.out_act + orow * p.ldo_act + gcol + c8, p.out_plane_stride,
+                                            ncol0 + c8 < p.N, v);
+                        if constexpr (mode_traits<OM>::f16) {             // fp16 range guard (ser_hip.h range_flag)
+                            if (p.range_flag) {
+#pragma unroll
+                                for (int r = 0; r < 8; r += 2) ramax = fmaxf(ramax, fmaxf(fabsf(v[r]), fabsf(v[r + 1])));
+                            }
+                        }
+                    }
                 }
             }
             if (p.stat_out) {
@@ -648,6 +881,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
         }
     }
+    if constexpr (mode_traits<OM>::f16) range_report(p.range_flag, ramax);
 #ifdef SER_GEMM_DBG
     {
         __builtin_amdgcn_sched_barrier(0);
@@ -690,12 +924,18 @@ template <int WM, int WN, int TM, int TN, int BK, int ST, bool LNEPI, bool X32 =
 static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const int npl = (a->mode == SER_MODE_FP32X || a->mode == SER_MODE_FP16X) ? 2 : 1;
-    const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8);   // ring (+ [BM][2] row statistics)
+    const int LDS = npl * ST * (BM + BN) * BK * 2 + (LNEPI ? 0 : BM * 8)    // ring (+ [BM][2] row statistics)
+                  + (a->mode == SER_MODE_FP16M ? ST * (BM + BN) * 4 : 0);   // FP16M: + the block-scale words of every stage
     const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a->groups, 1), block(64 * WM * WN, 1, 1);
     hipError_t e = hipSuccess;
     if constexpr (X32) {
         if constexpr (!LNEPI) {
+            if (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16M) {   // output projection of "f16m": 3 products on the attention kernel's hi + lo
+                if constexpr (BN >= 128)                                         // context rows, FP16M copy for FC1
+                    e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16X, LNEPI, SER_MODE_FP16M>(a, grid, block, LDS, s);
+                else return ser_fail(-22, "ser_gemm: FP16X -> FP16M output needs a dense tile (N > 64)");
+            } else
             if (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16)      // output projection of "f16a": 3 products, one-plane copy for FC1
                 e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16X, LNEPI, SER_MODE_FP16>(a, grid, block, LDS, s);
             else if (a->mode == SER_MODE_FP16X)        // attention block ("f16a") / logit path ("f16q"): 3 products on the f16 MFMA
@@ -711,6 +951,14 @@ static int launch_cfg(const ser_gemm_args* a, hipStream_t s) {
                 e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP32X, LNEPI>(a, grid, block, LDS, s);
         }
     } else {
+        if (a->mode == SER_MODE_FP16M) {
+            if constexpr (!LNEPI && BN >= 128 && BK == 64) {
+                if (a->out_mode == SER_MODE_FP16X)     // packed projection of "f16m": q, k, v leave as fp16 hi + lo planes for ser_attention
+                    e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16M, LNEPI, SER_MODE_FP16X>(a, grid, block, LDS, s);
+                else
+                    e = launch_mode<WM, WN, TM, TN, BK, ST, SER_MODE_FP16M, LNEPI>(a, grid, block, LDS, s);
+            } else return ser_fail(-22, "ser_gemm: FP16M needs a dense tile (N > 64, no LayerNorm epilogue)");
+        } else
         if (a->mode == SER_MODE_FP16) {
             if constexpr (!LNEPI && BN >= 128) {
                 if (a->out_mode == SER_MODE_FP16X)     // FC2 of the "f16q" mode: the next layer's q / k projection reads hi + lo planes
@@ -784,8 +1032,18 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->K % 64) return ser_fail(-3, "ser_gemm: K=%d must be a multiple of 64", a->K);
     if (a->kc && (a->kc % 64 || a->K % a->kc)) return ser_fail(-4, "ser_gemm: kc=%d must divide K and be a multiple of 64", a->kc);
     if (a->N % 8) return ser_fail(-5, "ser_gemm: N=%d must be a multiple of 8", a->N);
-    if (a->mode != SER_MODE_BF16 && a->mode != SER_MODE_FP32X && a->mode != SER_MODE_FP16 && a->mode != SER_MODE_FP16X)
+    if (a->mode != SER_MODE_BF16 && a->mode != SER_MODE_FP32X && a->mode != SER_MODE_FP16 && a->mode != SER_MODE_FP16X && a->mode != SER_MODE_FP16M)
         return ser_fail(-6, "ser_gemm: bad mode %d", a->mode);
+    if (a->mode == SER_MODE_FP16M) {
+        if (!a->a_scale || !a->w_scale || a->a_scale_ld < a->M || a->w_scale_ld < a->N)
+            return ser_fail(-23, "ser_gemm: FP16M needs a_scale / w_scale with *_scale_ld >= the row count");
+        if (a->a_rowoff || a->kc || a->groups != 1 || a->ln_gamma || (a->lda % 64))
+            return ser_fail(-23, "ser_gemm: FP16M takes plain row-major operands (no row map / conv chunks / groups / LayerNorm epilogue), lda %% 64 == 0");
+    }
+    if (a->out_mode == SER_MODE_FP16M || (a->mode == SER_MODE_FP16M && !a->out_mode && a->out_act)) {
+        if (!a->out_scale || (a->N % 64) || (a->ldo_act % 64) || a->groups != 1 || a->ln_gamma)
+            return ser_fail(-24, "ser_gemm: an FP16M out_act needs out_scale, N %% 64 == 0, ldo_act %% 64 == 0, groups == 1, no LayerNorm epilogue");
+    }
     if (!a->a_rowoff && (a->lda % 8)) return ser_fail(-7, "ser_gemm: lda must be a multiple of 8");
     if (a->groups < 1) return ser_fail(-8, "ser_gemm: groups=%d", a->groups);
     if (!a->out_f32 && !a->out_act) return ser_fail(-9, "ser_gemm: no output");
@@ -807,8 +1065,9 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->lnstat_out && !a->ln_stats_in) return ser_fail(-20, "ser_gemm: lnstat_out needs ln_stats_in");
     if (a->out_mode && a->out_mode != a->mode && !a->ln_gamma &&
         !((a->mode == SER_MODE_FP32X && a->out_mode == SER_MODE_FP16) || (a->mode == SER_MODE_FP16 && a->out_mode == SER_MODE_FP16X) ||
-          (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16)))
-        return ser_fail(-21, "ser_gemm: out_mode %d with mode %d (FP32X -> FP16, FP16 <-> FP16X convert)", a->out_mode, a->mode);
+          (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16) || (a->mode == SER_MODE_FP16X && a->out_mode == SER_MODE_FP16M) ||
+          (a->mode == SER_MODE_FP16M && a->out_mode == SER_MODE_FP16X)))
+        return ser_fail(-21, "ser_gemm: out_mode %d with mode %d (FP32X -> FP16, FP16 <-> FP16X, FP16X <-> FP16M convert)", a->out_mode, a->mode);
     if (a->out_mode && a->out_mode != a->mode && a->ln_gamma)
         return ser_fail(-21, "ser_gemm: out_mode %d with the LayerNorm epilogue", a->out_mode);
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
@@ -852,6 +1111,17 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         if (x32_sq_min > 0 && a->N >= 256 && t256sq >= x32_sq_min && sq_full && a->act == SER_ACT_NONE) return launch_cfg<4, 2, 4, 8, 32, 2, false, true>(a, s);
         if (x32_256_min > 0 && a->N >= 128 && t256x128 >= x32_256_min) return launch_cfg<4, 2, 4, 4, 32, 3, false, true>(a, s);
         return launch_cfg<4, 2, 2, 4, 64, 2, false, true>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
+    }
+    if (a->mode == SER_MODE_FP16M) {
+        // the single-plane tiles walked twice per K tile (H unit, E unit): 256x128 on a three-stage ring from 100 tiles up, 128x128 on four waves
+        // below that.  The 256x256 form (two stages of 64 KiB: one unit in flight) is built and exact but SLOWER at M = 7 984 -- packed projection
+        // 196 us against 126 us on 256x128, FC1 212 against 181 (profiles/r05_gemm_f16m_bench.txt) -- so only tile_cfg = 3 selects it
+        const long t256sq = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+        const long t256x128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128);
+        static const long m_sq_min = SER_KNOB("SER_GEMM_M16_SQ_MIN", 1L << 30), m_256_min = SER_KNOB("SER_GEMM_M16_256_MIN", 100);
+        if (a->tile_cfg == 3 || (!a->tile_cfg && a->N >= 256 && t256sq >= m_sq_min)) return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
+        if (a->tile_cfg == 2 || (!a->tile_cfg && a->N >= 128 && t256x128 >= m_256_min)) return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
+        return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
     }
     switch (pick_cfg(a)) {
         case CFG_LN512:   return launch_cfg<2, 4, 4, 8, 64, 2, true>(a, s);     // 160 KiB ring, one barrier per 64-deep K tile

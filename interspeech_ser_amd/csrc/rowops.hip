@@ -336,10 +336,12 @@ template <int MODE>
 __global__ __launch_bounds__(256) void row_center_kernel(const float* __restrict__ x, int64_t ldx,
                                                          unsigned short* __restrict__ oa, int64_t ldoa, int64_t plane,
                                                          float* __restrict__ stats, int stat_groups,
-                                                         float* __restrict__ shift, int rows, int D) {
+                                                         float* __restrict__ shift, int rows, int D,
+                                                         uint32_t* __restrict__ oscale, int64_t oscale_ld, uint32_t* __restrict__ rflag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    float ramax = 0.f;
     const float* xr = x + (int64_t)row * ldx;
     f32x4 v[8];
     float s = 0.f;
@@ -358,9 +360,19 @@ __global__ __launch_bounds__(256) void row_center_kernel(const float* __restrict
             f32x4 d;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { d[j] = v[i][j] - mean; q += d[j] * d[j]; r1 += d[j]; }
-            store_act4<MODE>(oa + (int64_t)row * ldoa + c, plane, d[0], d[1], d[2], d[3]);
+            if constexpr (MODE != SER_MODE_FP16M) store_act4<MODE>(oa + (int64_t)row * ldoa + c, plane, d[0], d[1], d[2], d[3]);
+            if constexpr (mode_traits<MODE>::f16 && MODE != SER_MODE_FP16M) ramax = fmaxf(ramax, fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))));
+        }
+        if constexpr (MODE == SER_MODE_FP16M) {                       // (D % 64 == 0: whole 32-column blocks; every lane joins the block shuffles)
+            if (i * 256 < D) {
+                const bool in = c < D;
+                const float d4[4] = {in ? v[i][0] - mean : 0.f, in ? v[i][1] - mean : 0.f, in ? v[i][2] - mean : 0.f, in ? v[i][3] - mean : 0.f};
+                ramax = fmaxf(ramax, mx_store_row<4>(d4, in, oa + (int64_t)row * ldoa, (unsigned char*)(oa + plane + (int64_t)row * ldoa), c,
+                                                     oscale + row, oscale_ld, false));
+            }
         }
     }
+    if constexpr (mode_traits<MODE>::f16) range_report(rflag, ramax);
     q = wave_sum(q);
     r1 = wave_sum(r1);
     float* st = stats + (int64_t)row * stat_groups * 2;
@@ -368,27 +380,36 @@ __global__ __launch_bounds__(256) void row_center_kernel(const float* __restrict
     if (lane == 0) shift[row] = mean;
 }
 
-extern "C" int ser_row_center(const float* x, int64_t ldx, void* out_act, int64_t ldo_act, int64_t out_plane_stride,
-                              float* stats, int stat_groups, float* shift, int mode, int rows, int D, void* stream) {
+extern "C" int ser_row_center_v(const ser_row_center_args* a, void* stream) {
+    if (!a) return ser_fail(-1, "ser_row_center: null pointer");
+    const float* x = a->x; const int64_t ldx = a->ldx, ldo_act = a->ldo_act, out_plane_stride = a->out_plane_stride;
+    void* out_act = a->out_act; float* stats = a->stats; float* shift = a->shift;
+    const int stat_groups = a->stat_groups, mode = a->mode, rows = a->rows, D = a->D;
     if (!x || !out_act || !stats || !shift) return ser_fail(-1, "ser_row_center: null pointer");
     if (D % 4 || D > 2048 || D <= 0 || rows <= 0) return ser_fail(-2, "ser_row_center: D=%d rows=%d unsupported", D, rows);
     if ((ldx % 4) || (ldo_act % 4) || stat_groups < 2 || (stat_groups & 1))
         return ser_fail(-3, "ser_row_center: pitches must be multiples of 4, stat_groups even and >= 2");
+    if (mode == SER_MODE_FP16M && (!a->out_scale || a->out_scale_ld < rows || (D % 64) || (ldo_act % 64)))
+        return ser_fail(-5, "ser_row_center: FP16M needs out_scale (out_scale_ld >= rows), D %% 64 == 0, ldo_act %% 64 == 0");
     dim3 grid((rows + 3) / 4), block(256);
-    if (mode == SER_MODE_FP32X)
-        hipLaunchKernelGGL(row_center_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, ldx,
-                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
-    else if (mode == SER_MODE_BF16)
-        hipLaunchKernelGGL(row_center_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx,
-                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
-    else if (mode == SER_MODE_FP16)
-        hipLaunchKernelGGL(row_center_kernel<SER_MODE_FP16>, grid, block, 0, (hipStream_t)stream, x, ldx,
-                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
-    else if (mode == SER_MODE_FP16X)
-        hipLaunchKernelGGL(row_center_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, ldx,
-                           (unsigned short*)out_act, ldo_act, out_plane_stride, stats, stat_groups, shift, rows, D);
+#define SER_RC(M_) hipLaunchKernelGGL(row_center_kernel<M_>, grid, block, 0, (hipStream_t)stream, x, ldx, (unsigned short*)out_act, ldo_act, \
+                                      out_plane_stride, stats, stat_groups, shift, rows, D, a->out_scale, a->out_scale_ld, a->range_flag)
+    if (mode == SER_MODE_FP32X) SER_RC(SER_MODE_FP32X);
+    else if (mode == SER_MODE_BF16) SER_RC(SER_MODE_BF16);
+    else if (mode == SER_MODE_FP16) SER_RC(SER_MODE_FP16);
+    else if (mode == SER_MODE_FP16X) SER_RC(SER_MODE_FP16X);
+    else if (mode == SER_MODE_FP16M) SER_RC(SER_MODE_FP16M);
     else return ser_fail(-4, "ser_row_center: bad mode %d", mode);
+#undef SER_RC
     return ser_check_launch("ser_row_center");
+}
+
+extern "C" int ser_row_center(const float* x, int64_t ldx, void* out_act, int64_t ldo_act, int64_t out_plane_stride,
+                              float* stats, int stat_groups, float* shift, int mode, int rows, int D, void* stream) {
+    ser_row_center_args a = {};
+    a.x = x; a.ldx = ldx; a.out_act = out_act; a.ldo_act = ldo_act; a.out_plane_stride = out_plane_stride; a.stats = stats; a.shift = shift;
+    a.stat_groups = stat_groups; a.mode = mode; a.rows = rows; a.D = D;
+    return ser_row_center_v(&a, stream);
 }
 
 // ------------------------------------------------------------------ text embeddings (8f-1)
@@ -667,4 +688,37 @@ extern "C" int ser_pack_act(const float* x, int B, int C, int T, int halo, void*
         hipLaunchKernelGGL(pack_act_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
                            (unsigned short*)out, ldo, out_plane_stride);
     return ser_check_launch("ser_pack_act");
+}
+
+// ------------------------------------------------------------------ SER_MODE_FP16M packing
+// fp32 [rows][ldx] -> hi plane + e4m3 cross-term plane + block scales (ser_hip.h).  A lane owns 8 consecutive columns, 4 lanes a 32-column
+// scale block, 8 lanes a 64-column tile; a wave walks 512 columns of one row at a time.  Weights at load, kernel tests.
+__global__ __launch_bounds__(256) void pack_f16m_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols,
+                                                        unsigned short* __restrict__ out, int64_t ldo, int64_t plane,
+                                                        uint32_t* __restrict__ scales, int64_t sld, int weight, uint32_t* __restrict__ rflag) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float ramax = 0.f;
+    for (int c0 = 0; c0 < cols; c0 += 512) {
+        const int c = c0 + lane * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c < cols) {
+            const f32x4 a = *(const f32x4*)(x + (int64_t)row * ldx + c), b = *(const f32x4*)(x + (int64_t)row * ldx + c + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        }
+        ramax = fmaxf(ramax, mx_store_row<8>(v, c < cols, out + (int64_t)row * ldo, (unsigned char*)(out + plane + (int64_t)row * ldo), c,
+                                             scales + row, sld, weight != 0));
+    }
+    range_report(rflag, ramax);
+}
+
+extern "C" int ser_pack_f16m(const float* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int64_t plane_stride,
+                             uint32_t* scales, int64_t scale_ld, int is_weight, uint32_t* range_flag, void* stream) {
+    if (!x || !out || !scales) return ser_fail(-1, "ser_pack_f16m: null pointer");
+    if (rows <= 0 || cols <= 0 || (cols % 64) || (ldo % 64) || (ldx % 4) || scale_ld < rows || ldo < cols)
+        return ser_fail(-2, "ser_pack_f16m: rows=%d cols=%d (cols %% 64 == 0, ldo %% 64 == 0, ldx %% 4 == 0, scale_ld >= rows)", rows, cols);
+    hipLaunchKernelGGL(pack_f16m_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols,
+                       (unsigned short*)out, ldo, plane_stride, scales, scale_ld, is_weight, range_flag);
+    return ser_check_launch("ser_pack_f16m");
 }

@@ -42,8 +42,9 @@ __device__ __forceinline__ float h2f(unsigned short h) {
 }
 // element format / plane count of a numerics mode's operand tensors
 template <int MODE> struct mode_traits {
-    static constexpr bool f16 = (MODE == SER_MODE_FP16 || MODE == SER_MODE_FP16X || MODE == SER_MODE_FP16Q);      // IEEE fp16 elements (else bf16)
-    static constexpr int planes = (MODE == SER_MODE_FP32X || MODE == SER_MODE_FP16X || MODE == SER_MODE_FP16Q) ? 2 : 1;   // FP16Q (ser_attention): of q, k
+    static constexpr bool f16 = (MODE == SER_MODE_FP16 || MODE == SER_MODE_FP16X || MODE == SER_MODE_FP16Q || MODE == SER_MODE_FP16M);      // IEEE fp16 elements (else bf16)
+    // FP16Q (ser_attention): of q, k.  FP16M: plane 1 is the 8-bit cross-term plane (ser_hip.h), not a 16-bit lo plane -- its users take the mx_* helpers below
+    static constexpr int planes = (MODE == SER_MODE_FP32X || MODE == SER_MODE_FP16X || MODE == SER_MODE_FP16Q || MODE == SER_MODE_FP16M) ? 2 : 1;
 };
 // one 16-bit operand element -> fp32, in the format of MODE's planes
 template <int MODE>
@@ -305,4 +306,89 @@ __device__ __forceinline__ void load_act8(const unsigned short* src, int64_t pla
             v[2 * i + 1] += __uint_as_float(l[i] & 0xffff0000u);
         }
     }
+}
+
+// ---- SER_MODE_FP16M (include/ser_hip.h): fp16 hi plane + block-scaled e4m3 cross-term plane ---------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+#define SER_F16_MAX 65504.0f
+// E8M0 code of the smallest power of two s with amax / s <= 448 (e4m3's largest value): ceil(log2(amax / 448)) + 127 in [1, 254].
+// (amax / 448 is rounded once: a block whose quotient lands a hair above 448 still converts to 448 -- v_cvt_pk_fp8_f32 rounds up to 464 down.)
+__device__ __forceinline__ unsigned mx_code(float amax) {
+    const unsigned c = (__float_as_uint(amax * (1.0f / 448.0f)) + 0x7fffffu) >> 23;
+    return c < 1u ? 1u : (c > 254u ? 254u : c);
+}
+__device__ __forceinline__ float mx_inv(unsigned code) { return __uint_as_float((254u - code) << 23); }     // 2^(127 - code)
+// four fp32 (already divided by their block scale) -> four e4m3 bytes, element 0 in the low byte (v_cvt_pk_fp8_f32: OCP e4m3fn, RNE)
+__device__ __forceinline__ unsigned mx_pack4(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
+// max over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the lanes of one accumulator row in the 16x16 MFMA layouts): two swaps, no LDS
+__device__ __forceinline__ float max_rowquad(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+// 4 x 4 transpose of one dword per (lane row fq = lane >> 4, register j): afterwards register j of row fq holds what register fq of row j held.
+// v_permlane32_swap exchanges the off-diagonal 2 x 2 blocks, v_permlane16_swap transposes inside every 2 x 2 block.
+__device__ __forceinline__ void transpose_rowquad(unsigned (&r)[4]) {
+    const auto a0 = __builtin_amdgcn_permlane32_swap(r[0], r[2], false, false);
+    const auto a1 = __builtin_amdgcn_permlane32_swap(r[1], r[3], false, false);
+    const auto b0 = __builtin_amdgcn_permlane16_swap(a0[0], a1[0], false, false);
+    const auto b1 = __builtin_amdgcn_permlane16_swap(a0[1], a1[1], false, false);
+    r[0] = b0[0]; r[1] = b0[1]; r[2] = b1[0]; r[3] = b1[1];
+}
+// Row kernels: VPL (4 or 8) consecutive values of one row per lane, 32 / VPL consecutive lanes per scale block, 64 / VPL per 64-column tile.
+//   hi_row: the row in plane 0; x8_row: the same row in plane 1 (as bytes); col: the lane's first column (multiple of VPL);
+//   srow: scale words of this row (tile t at srow[t * sld]); weight: plane roles (ser_hip.h); every lane of the wave must call (shuffles) --
+//   `ok` gates the stores of lanes past the end of the row.  Returns max |value| of the lane (for the fp16 range guard).
+template <int VPL>
+__device__ __forceinline__ float mx_store_row(const float (&v)[VPL], bool ok, unsigned short* hi_row, unsigned char* x8_row, int col,
+                                              uint32_t* srow, int64_t sld, bool weight) {
+    static_assert(VPL == 4 || VPL == 8, "4 or 8 values per lane");
+    constexpr int LPB = 32 / VPL;
+    float lo[VPL], ax = 0.f, al = 0.f;
+    unsigned hp[VPL / 2];
+#pragma unroll
+    for (int i = 0; i < VPL; i += 2) {
+        hp[i / 2] = pack_h2(v[i], v[i + 1]);
+        lo[i] = v[i] - h2f((unsigned short)(hp[i / 2] & 0xffffu));
+        lo[i + 1] = v[i + 1] - h2f((unsigned short)(hp[i / 2] >> 16));
+        ax = fmaxf(ax, fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
+        al = fmaxf(al, fmaxf(fabsf(lo[i]), fabsf(lo[i + 1])));
+    }
+    const float amax_lane = ax;
+#pragma unroll
+    for (int o = 1; o < LPB; o <<= 1) { ax = fmaxf(ax, __shfl_xor(ax, o, 64)); al = fmaxf(al, __shfl_xor(al, o, 64)); }
+    const unsigned cx = mx_code(ax), cl = mx_code(al);
+    const float ix = mx_inv(cx), il = mx_inv(cl);
+    unsigned bx[VPL / 4], bl[VPL / 4];
+#pragma unroll
+    for (int i = 0; i < VPL; i += 4) {
+        bx[i / 4] = mx_pack4(v[i] * ix, v[i + 1] * ix, v[i + 2] * ix, v[i + 3] * ix);
+        bl[i / 4] = mx_pack4(lo[i] * il, lo[i + 1] * il, lo[i + 2] * il, lo[i + 3] * il);
+    }
+    // scale word of the lane's 64-column tile: codes of its two blocks, [P0, P1, Q0, Q1]
+    const unsigned cp = weight ? cx : cl, cq = weight ? cl : cx;
+    const unsigned cp1 = __shfl_xor(cp, LPB, 64), cq1 = __shfl_xor(cq, LPB, 64);      // the tile's other block
+    if (ok) {
+        if constexpr (VPL == 8) *(u32x4*)(hi_row + col) = (u32x4){hp[0], hp[1], hp[2], hp[3]};
+        else *(u32x2*)(hi_row + col) = (u32x2){hp[0], hp[1]};
+        unsigned char* seg = x8_row + (col & ~63) * 2;                               // 128 bytes per 64-column tile
+        unsigned char* pp = seg + (col & 63), *qq = pp + 64;
+        if constexpr (VPL == 8) {
+            *(u32x2*)pp = weight ? (u32x2){bx[0], bx[1]} : (u32x2){bl[0], bl[1]};
+            *(u32x2*)qq = weight ? (u32x2){bl[0], bl[1]} : (u32x2){bx[0], bx[1]};
+        } else {
+            *(unsigned*)pp = weight ? bx[0] : bl[0];
+            *(unsigned*)qq = weight ? bl[0] : bx[0];
+        }
+        if ((col & 63) == 0) srow[(int64_t)(col >> 6) * sld] = cp | (cp1 << 8) | (cq << 16) | (cq1 << 24);
+    }
+    return amax_lane;
+}
+__device__ __forceinline__ void range_report(uint32_t* flag, float amax) {
+    if (flag && !(amax <= SER_F16_MAX)) atomicOr(flag, 1u);                           // NaN reports too
 }

@@ -30,7 +30,12 @@ from ._lib import GemmArgs, check, lib
 from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
 MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16,
-         "f16x": _lib.MODE_FP16X}
+         "f16x": _lib.MODE_FP16X, "f16m": _lib.MODE_FP16M}
+# "f16m" (round 5): the encoder layers' GEMMs on SER_MODE_FP16M operands -- fp16 main product + block-scaled e4m3 cross terms on gfx950's
+# v_mfma_scale_f32_16x16x128_f8f6f4: 2 product-equivalents per algorithmic FLOP instead of "f16x"'s 3 (include/ser_hip.h).  The packed
+# projection, FC1 and FC2 multiply in it; ser_attention and the output projection (8 % of the layer FLOPs, its A operand is the attention
+# kernel's fp16 hi + lo context rows) and the conv stem stay on fp16 hi + lo planes.  Operand error ~2^-15 (between "f16"'s 2^-11 and
+# "f16x"'s 2^-22): oracle/numerics_whatif_f16m.py, tests/test_gpu_depth.py.
 # "f16x" (round 4): the 3-product split EVERYWHERE, like "fp32x", on fp16 hi + lo planes -- 22-bit operands instead of the 16 of the
 # bf16 pair at the same cost.  The widest margin of all modes where |values| stay inside fp16's range (65 504).
 # "f16": encoder layers on single-product fp16 operands (11 significand bits at the bf16 MFMA rate), the convolutional
@@ -43,9 +48,11 @@ MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16
 # the feed-forward pair (62 % of the layer FLOPs) on single fp16 products.  oracle/numerics_whatif.py: under sharp attention the
 # error comes from the attention block as a whole -- rounding v, P, the context rows or the output-projection weights once is
 # amplified by the following layers' softmax as much as rounding q and k -- while the feed-forward rounding is benign.
-_PLANES = {_lib.MODE_BF16: 1, _lib.MODE_FP32X: 2, _lib.MODE_FP16: 1, _lib.MODE_FP16X: 2}
+_PLANES = {_lib.MODE_BF16: 1, _lib.MODE_FP32X: 2, _lib.MODE_FP16: 1, _lib.MODE_FP16X: 2, _lib.MODE_FP16M: 2}
 _DTYPE = {_lib.MODE_BF16: torch.bfloat16, _lib.MODE_FP32X: torch.bfloat16, _lib.MODE_FP16: torch.float16,
-          _lib.MODE_FP16X: torch.float16}
+          _lib.MODE_FP16X: torch.float16, _lib.MODE_FP16M: torch.float16}
+# MFMA products per algorithmic FLOP of a GEMM launch in each operand format (FP16M: the scaled e4m3 instruction runs at twice the fp16 rate)
+_PRODUCTS = {_lib.MODE_BF16: 1, _lib.MODE_FP32X: 3, _lib.MODE_FP16: 1, _lib.MODE_FP16X: 3, _lib.MODE_FP16M: 2}
 
 
 # A/B knob (tools/): SER_NO_SHIFT=1 turns the shifted operand copy of the encoder layers off (state 0 is still centred)
@@ -146,11 +153,14 @@ class Act:
     """16-bit GEMM operand with 1 (bf16 / fp16) or 2 (bf16 hi/lo) planes: tensor [planes, rows, cols]."""
 
     def __init__(self, rows: int, cols: int, planes: int, device, zero: bool = False, extra_rows: int = 0,
-                 dtype=torch.bfloat16):
+                 dtype=torch.bfloat16, mx: bool = False):
         alloc = torch.zeros if zero else torch.empty
         self.t = alloc((planes, rows + extra_rows, cols), dtype=dtype, device=device)
         self.rows, self.cols, self.planes = rows, cols, planes
         self.plane_stride = (rows + extra_rows) * cols
+        # SER_MODE_FP16M: plane 1 holds the e4m3 cross-term bytes; one uint32 of four block-scale codes per (64-column tile, row)
+        self.scale = torch.zeros((cols // 64, rows + extra_rows), dtype=torch.int32, device=device) if mx else None
+        self.scale_ld = rows + extra_rows
 
     @property
     def ptr(self) -> int:
@@ -158,6 +168,8 @@ class Act:
 
     def float(self) -> torch.Tensor:
         """fp32 view for tests (hi + lo)."""
+        if self.scale is not None:
+            raise NotImplementedError("FP16M tensors: plane 1 is not a 16-bit lo plane")
         return self.t[:, : self.rows].float().sum(dim=0)
 
 
@@ -168,6 +180,7 @@ class Linear:
     N: int
     K: int
     colsum: Optional[torch.Tensor] = None   # [N] fp32: sum_k of the stored (gamma-folded) planes, deferred LayerNorm
+    wscale: Optional[torch.Tensor] = None   # SER_MODE_FP16M: [K / 64, N] int32 block-scale words
 
 
 class HiddenStates:
@@ -217,10 +230,16 @@ class _EncoderBase:
         # planes (22-bit operands, round 3) rather than bf16 hi + lo (16-bit, the "fp32x" mode's): same cost, and the stem's share of the error
         # -- which sharp attention amplifies like any other -- drops by the 6 extra bits per operand
         self.stem_mode = (_lib.MODE_FP16X if _STEM_F16X else _lib.MODE_FP32X) if mode in ("f16", "f16q", "f16a") else self.mode
-        self.gate_in_attn = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1"    # WavLM gate inside ser_attention (see the note at the top)
+        if mode == "f16m":
+            self.stem_mode = _lib.MODE_FP16X
+        # WavLM gate inside ser_attention (see the note at the top).  "f16m": as 2H columns of the packed projection instead -- the in-kernel form
+        # multiplies the layer input's operand copy, whose second plane is e4m3 bytes in that mode
+        self.gate_in_attn = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1" and mode != "f16m"
         self.qk_mode = _lib.MODE_FP16X if mode == "f16q" else None             # logit path on its own launch (None: one packed launch)
-        self.attn_mode = _lib.MODE_FP16X if mode == "f16a" else self.mode      # packed projection, context rows, output projection
-        self.x_mode = self.qk_mode or self.attn_mode                           # format of the operand copy the packed projection reads
+        self.attn_mode = _lib.MODE_FP16X if mode in ("f16a", "f16m") else self.mode   # attention kernel, context rows, output projection
+        self.qkv_mode = _lib.MODE_FP16M if mode == "f16m" else self.attn_mode  # packed projection
+        self.x_mode = self.qk_mode or self.qkv_mode                            # format of the operand copy the packed projection reads
+        self.qkv_out_mode = self.attn_mode if mode == "f16m" else self.x_mode  # format of q, k, v (what ser_attention reads)
         self.planes, self.stem_planes = _PLANES[self.mode], _PLANES[self.stem_mode]
         self._cache: Dict = {}
         # when a list, every ser_gemm launch appends (start_event, end_event, algorithmic_flops):
@@ -260,6 +279,13 @@ class _EncoderBase:
         if mode is None:
             mode = self.stem_mode if stem else self.mode
         out = torch.empty((_PLANES[mode], N, K), dtype=_DTYPE[mode], device=self.device)
+        if mode == _lib.MODE_FP16M:
+            if K % 64:
+                raise ValueError(f"FP16M weights need K % 64 == 0 (K = {K})")
+            wscale = torch.zeros((K // 64, N), dtype=torch.int32, device=self.device)
+            check(lib.ser_pack_f16m(src.data_ptr(), K, N, K, out.data_ptr(), K, N * K, wscale.data_ptr(), N, 1, None, _stream()), "ser_pack_f16m")
+            torch.cuda.current_stream().synchronize()
+            return Linear(out, None if b is None else self._dev_f32(b), N, K, wscale=wscale)
         check(lib.ser_split_bf16(src.data_ptr(), out.data_ptr(), N * K, mode, N * K, _stream()), "ser_split_bf16")
         torch.cuda.current_stream().synchronize()
         return Linear(out, None if b is None else self._dev_f32(b), N, K)
@@ -275,13 +301,16 @@ class _EncoderBase:
         if b is not None:
             t = t + b.detach().double()
         lin.b = self._dev_f32(t.float())
-        lin.colsum = lin.w.double().sum(dim=(0, 2)).float().contiguous()
+        if lin.wscale is not None:          # FP16M: the effective weight is w_hi + (the e4m3 image of) w_lo = the fp32 fold to ~2^-15
+            lin.colsum = self._dev_f32((w64 * g64[None, :]).float().double().sum(dim=1).float())
+        else:
+            lin.colsum = lin.w.double().sum(dim=(0, 2)).float().contiguous()
         return lin
 
     def _new_act(self, rows, cols, zero=False, extra_rows=0, stem=False, mode: Optional[int] = None) -> Act:
         if mode is None:
             mode = self.stem_mode if stem else self.mode
-        return Act(rows, cols, _PLANES[mode], self.device, zero=zero, extra_rows=extra_rows, dtype=_DTYPE[mode])
+        return Act(rows, cols, _PLANES[mode], self.device, zero=zero, extra_rows=extra_rows, dtype=_DTYPE[mode], mx=(mode == _lib.MODE_FP16M))
 
     # ------------------------------------------------------------------ launchers
     def _gemm(self, a: Act, lin: Linear, M: int, *, a_rowoff=None, lda=None, kc=0, ldj=0, groups=1,
@@ -332,6 +361,13 @@ class _EncoderBase:
         if ln_mean is not None:                 # consumer side: (shift of the A rows, absolute row mean out)
             g.ln_shift, g.mean_out = _ptr(ln_mean[0]), ln_mean[1].data_ptr()
         g.lnstat_out = _ptr(lnstat_out)         # (relative mean, rstd) of the A rows for the attention kernel's in-kernel gate
+        if g.mode == _lib.MODE_FP16M:           # block scales of both operands
+            g.a_scale, g.a_scale_ld = a.scale.data_ptr(), a.scale_ld
+            g.w_scale, g.w_scale_ld = lin.wscale.data_ptr(), lin.wscale.shape[1]
+        if out_act is not None and (g.out_mode or g.mode) == _lib.MODE_FP16M:
+            if out_col % 64:
+                raise ValueError("an FP16M output must start on a 64-column tile")
+            g.out_scale, g.out_scale_ld = out_act.scale.data_ptr() + 4 * (out_col // 64) * out_act.scale_ld, out_act.scale_ld
         if rec is not None:
             rec.commit(_lib.OP_GEMM, g, M=M)
             return
@@ -349,12 +385,16 @@ class _EncoderBase:
         nbytes = 2.0 * planes * (M * k_real * groups + g.N * groups * k_real)
         nbytes += 4.0 * M * g.N * groups * ((residual is not None) + (out_f32 is not None))
         nbytes += 2.0 * planes * M * g.N * groups * (out_act is not None)
-        self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * k_real, nbytes, 3 if _PLANES[g.mode] == 2 else 1))
+        self.gemm_trace.append((e0, e1, 2.0 * M * g.N * groups * k_real, nbytes, _PRODUCTS[g.mode]))
 
     def _layernorm(self, x: torch.Tensor, ldx: int, ln, rows: int, D: int, *, gelu=False, out_f32=None,
                    out_act: Optional[Act] = None, eps=None, stem=False):
         g, b = ln
         mode = self.stem_mode if stem else self.mode
+        if mode == _lib.MODE_FP16M:                   # ser_layernorm writes no FP16M copy; the encoders only need its fp32 output in that mode
+            if out_act is not None:
+                raise NotImplementedError("ser_layernorm has no FP16M operand copy")
+            mode = _lib.MODE_FP16X
         eps = float(self.geo.layer_norm_eps if eps is None else eps)
         o_act = None if out_act is None else out_act.ptr
         ldo_act = 0 if out_act is None else out_act.cols
@@ -379,10 +419,16 @@ class _EncoderBase:
             a = rec.slot("row_center")
             a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride = x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride
             a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.x_mode, rows, D
+            if out_act.scale is not None:
+                a.out_scale, a.out_scale_ld = out_act.scale.data_ptr(), out_act.scale_ld
             rec.commit(_lib.OP_ROW_CENTER, a, rows=rows)
             return
-        check(lib.ser_row_center(x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride, stats.data_ptr(), groups,
-                                 shift.data_ptr(), self.x_mode, rows, D, self._s()), "ser_row_center")
+        a = _lib.RowCenterArgs()
+        a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride = x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride
+        a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.x_mode, rows, D
+        if out_act.scale is not None:
+            a.out_scale, a.out_scale_ld = out_act.scale.data_ptr(), out_act.scale_ld
+        check(lib.ser_row_center_v(C.byref(a), self._s()), "ser_row_center")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
                    gru_const=None, key_lens=None, bias2d=None, gate_in=None):
@@ -438,7 +484,7 @@ class _EncoderBase:
         lnstat = pl["gst"] if "gate_w" in lay else None     # (relative mean, rstd) per row for the attention kernel's in-kernel gate
         if self.qk_mode is None:
             self._gemm(pl["xa"], lay["qkv"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
-                       col_scale_end=D, ln_mean=ln_mean, mode=self.attn_mode, lnstat_out=lnstat)
+                       col_scale_end=D, ln_mean=ln_mean, mode=self.qkv_mode, out_mode=self.qkv_out_mode, lnstat_out=lnstat)
             return
         self._gemm(pl["xa"], lay["qk"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
                    col_scale_end=D, ln_mean=ln_mean, mode=self.qk_mode, lnstat_out=lnstat)
@@ -576,7 +622,7 @@ class _EncoderBase:
             bs.append(torch.cat([torch.stack([b8[:4].sum(), b8[4:].sum()]).repeat(H), torch.zeros(pad, device=wdev)]))
             lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
         if self.qk_mode is None:
-            lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=self.attn_mode)
+            lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=self.qkv_mode)
         else:
             # logit path [q | k | gate] on fp16 hi + lo planes (3 products), [v] on one fp16 plane
             lay["qk"] = self._linear_ln(torch.cat(ws[:2] + ws[3:], 0), torch.cat(bs[:2] + bs[3:], 0), sd[ln1 + ".weight"],
@@ -607,7 +653,7 @@ class _EncoderBase:
         pl["gst"] = torch.zeros((M, 2), dtype=torch.float32, device=dev)  # (relative mean, rstd) of x's rows (packed projection -> attention's gate)
         pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
         pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
-        pl["qkv"] = self._new_act(M, nqkv, mode=self.x_mode)      # "f16q": q, k, gate columns carry a lo plane, v's stays unused
+        pl["qkv"] = self._new_act(M, nqkv, mode=self.qkv_out_mode)   # "f16q": q, k, gate columns carry a lo plane, v's stays unused
         pl["ctx"] = self._new_act(M, D, mode=self.attn_mode)
         pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         pl["ffn"] = self._new_act(M, Fd)
@@ -722,7 +768,7 @@ class SpeechEncoder(_EncoderBase):
         # 128 x 120 = 15 360-long sums do feel fp16 operands (7.0e-4 -> 8.3e-4 at full geometry), so they stay on the stem format.
         # "f16q" / "f16a" keep it on the stem format always: an error in hidden_states[0] enters layer 0's logits, and these modes
         # exist for attention maps sharp enough to amplify it (LoRA stress fixture: 1.4e-3 -> see DESIGN.md section 4)
-        self.pos_in_stem = (self.mode_name == "f16" and Cg * k > 128 * 80) or self.mode_name in ("f16q", "f16a")
+        self.pos_in_stem = (self.mode_name == "f16" and Cg * k > 128 * 80) or self.mode_name in ("f16q", "f16a", "f16m")
         self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"], stem=self.pos_in_stem)
         self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
         self.layers = []
@@ -1163,7 +1209,7 @@ class TextEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != FAMILY_ROBERTA:
             raise ValueError("TextEncoder needs a roberta geometry")
-        if mode in ("f16", "f16q", "f16a"):
+        if mode in ("f16", "f16q", "f16a", "f16m"):
             raise ValueError("the text encoders support the bf16, fp32x and f16x numerics modes")
         sd = state_dict
         D = geo.hidden
@@ -1275,7 +1321,7 @@ class DebertaEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != "deberta":
             raise ValueError("DebertaEncoder needs a deberta geometry")
-        if mode in ("f16", "f16q", "f16a"):
+        if mode in ("f16", "f16q", "f16a", "f16m"):
             raise ValueError("the text encoders support the bf16, fp32x and f16x numerics modes")
         if geo.head_dim != 64:
             raise ValueError("DeBERTa path: head dim must be 64 (K of the position GEMMs; deberta-v3 base/large have 64)")

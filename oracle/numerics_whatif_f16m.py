@@ -1,0 +1,154 @@
+"""ANALYSIS / TEST INFRASTRUCTURE ONLY (never imported by the product).  CPU what-if for the "f16m" numerics mode (no GPU), at FULL depth:
+the encoder layers in fp64 with the operand roundings of a candidate GEMM arithmetic switched on, before any kernel is written.
+
+    python oracle/numerics_whatif_f16m.py [wavlm|hubert] [plain|sharp2|lora|outliers] [seconds]
+
+Candidate arithmetics of  y = x W^T  (x, W in fp64; every one accumulates exactly -- only OPERAND formats differ):
+    f16      one fp16 plane per operand                                   (the "f16" mode's layers)
+    bf16x3   bf16 hi + lo planes, hi*hi + lo*hi + hi*lo                    ("fp32x")
+    f16x     fp16 hi + lo planes, three products                           ("f16x", the drivers' default)
+    f16m8    fp16 hi*hi  +  e4m3(lo_x)*e4m3(hi_w) + e4m3(hi_x)*e4m3(lo_w)  with one power-of-two scale per 32 consecutive k of a row
+             (the OCP MX block format the gfx950 v_mfma_scale_f32_16x16x128_f8f6f4 instruction consumes)
+    f16m6    the same with e2m3 (fp6) cross-term planes
+The attention core (q, k, v, P, context rows) keeps fp16 hi + lo planes in the f16m variants, as the HIP path's ser_attention does.
+Error form of the tests: max|a - b| / max(1, max|b|) per hidden state, worst state, against the all-exact fp64 run.
+Follows HF modeling_wavlm.py:147-241,288-295,355-373 (reference call site preprocessing/preprocess_speech.py:50,66) through oracle.ssl_oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from interspeech_ser_amd import config as C                              # noqa: E402
+from oracle import ssl_oracle as O                                        # noqa: E402  (checker-side code)
+
+
+def r16(t):
+    return t.to(torch.float16).double()
+
+
+def rbf(t):
+    return t.to(torch.bfloat16).double()
+
+
+def minifloat(t, mbits, emin, vmax):
+    """round-to-nearest-even onto a sign + exponent + mbits-mantissa grid with subnormals below 2^emin, saturating at vmax"""
+    a = t.abs().clamp(max=vmax)
+    e = torch.floor(torch.log2(a.clamp(min=1e-300))).clamp(min=emin)
+    q = torch.pow(2.0, e - mbits)
+    return torch.sign(t) * torch.round(a / q) * q                          # torch.round: half to even
+
+
+def mx_quant(t, kind):
+    """[rows, K] -> block-scaled (32 consecutive k per block, scale = the smallest power of two that brings the block into range) minifloat"""
+    mbits, emin, vmax = {"e4m3": (3, -6, 448.0), "e2m3": (3, 0, 7.5)}[kind]
+    R, K = t.shape
+    b = t.reshape(R, K // 32, 32)
+    amax = b.abs().amax(-1, keepdim=True)
+    code = torch.ceil(torch.log2((amax / vmax).clamp(min=2.0 ** -126)))
+    s = torch.pow(2.0, code)
+    return (minifloat(b / s, mbits, emin, vmax) * s).reshape(R, K)
+
+
+def mm(x, W, arith):
+    if arith == "exact":
+        return x @ W.T
+    if arith == "f16":
+        return r16(x) @ r16(W).T
+    if arith == "bf16x3":
+        xh, wh = rbf(x), rbf(W)
+        xl, wl = rbf(x - xh), rbf(W - wh)
+        return xh @ wh.T + xl @ wh.T + xh @ wl.T
+    xh, wh = r16(x), r16(W)
+    if arith == "f16x":
+        xl, wl = r16(x - xh), r16(W - wh)
+        return xh @ wh.T + xl @ wh.T + xh @ wl.T
+    kind = {"f16m8": "e4m3", "f16m6": "e2m3"}[arith]
+    xl, wl = x - xh, W - wh
+    return xh @ wh.T + mx_quant(xl, kind) @ mx_quant(W, kind).T + mx_quant(x, kind) @ mx_quant(wl, kind).T
+
+
+def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
+    """sites: which GEMMs run `arith`; the others and the attention core run fp16 hi + lo planes ('f16x')."""
+    A = lambda site: arith if site in sites else "f16x"                    # noqa: E731
+    eps, H, dh, D = geo.layer_norm_eps, geo.heads, geo.head_dim, geo.hidden
+    sd = {k: v.double() for k, v in sd.items()}
+    h = h0.double()
+    T = h.shape[0]
+    table = O.relative_bias_table(geo, {k: v.float() for k, v in sd.items()}, T).double() if geo.family == "wavlm" else None
+    core = (lambda t: t) if arith == "exact" else (lambda t: r16(t) + r16(t - r16(t)))
+    states = []
+
+    def deferred_ln_linear(x, lnp, W, b, site):
+        mu = x.mean(-1, keepdim=True)
+        var = x.var(-1, unbiased=False, keepdim=True)
+        g, be = sd[lnp + ".weight"], sd[lnp + ".bias"]
+        return mm(x - mu, W * g[None, :], A(site)) * torch.rsqrt(var + eps) + (W @ be + (b if b is not None else 0.0))
+
+    for i in range(geo.num_layers):
+        states.append(h)
+        p = f"encoder.layers.{i}"
+        a = p + ".attention"
+        Wq, Wk, Wv = (sd[a + f".{n}_proj.weight"] for n in "qkv")
+        bq, bk, bv = (sd[a + f".{n}_proj.bias"] for n in "qkv")
+        for n in ("q", "v"):                                                # LoRA adapters, merged like weights.merge_lora does
+            if a + f".{n}_proj.lora_A.weight" in sd:
+                delta = float(sd["lora_scale"]) * sd[a + f".{n}_proj.lora_B.weight"] @ sd[a + f".{n}_proj.lora_A.weight"]
+                if n == "q":
+                    Wq = Wq + delta
+                else:
+                    Wv = Wv + delta
+        q = deferred_ln_linear(h, p + ".layer_norm", Wq, bq, "qkv") * dh ** -0.5
+        k = deferred_ln_linear(h, p + ".layer_norm", Wk, bk, "qkv")
+        v = deferred_ln_linear(h, p + ".layer_norm", Wv, bv, "qkv")
+        qh, kh, vh = (O._heads(core(t), H) for t in (q, k, v))
+        scores = qh @ kh.transpose(1, 2)
+        if geo.family == "wavlm":
+            x_ln = F.layer_norm(h, (D,), sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"], eps)
+            gate = O.wavlm_gate(geo, sd, a, x_ln)
+            idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None]) + (T - 1)
+            scores = scores + gate[:, :, None] * table[:, idx]
+        P = torch.softmax(scores, dim=-1)
+        ctx = (core(P) @ vh).permute(1, 0, 2).reshape(T, D)
+        h = h + mm(ctx, sd[a + ".out_proj.weight"], A("out")) + sd[a + ".out_proj.bias"]
+        f = F.gelu(deferred_ln_linear(h, p + ".final_layer_norm", sd[p + ".feed_forward.intermediate_dense.weight"],
+                                      sd[p + ".feed_forward.intermediate_dense.bias"], "fc1"))
+        h = h + mm(f, sd[p + ".feed_forward.output_dense.weight"], A("fc2")) + sd[p + ".feed_forward.output_dense.bias"]
+    states.append(F.layer_norm(h, (D,), sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"], eps))
+    return states
+
+
+def main():
+    import depth_envelope as DE
+    model = sys.argv[1] if len(sys.argv) > 1 else "wavlm"
+    kind = sys.argv[2] if len(sys.argv) > 2 else "sharp2"
+    seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 5.0
+    geo = C.geometry_for(DE.MODELS[model])
+    ref_sd, _ = DE.case_state_dicts(geo, kind)
+    wave = DE.clip(101, seconds)
+    with torch.no_grad():
+        x = torch.from_numpy(O.zero_mean_unit_var(wave))
+        base = {k: v for k, v in ref_sd.items() if "lora" not in k}
+        feats = O.conv_feature_encoder(geo, base, x)
+        h0 = O.feature_projection(geo, base, feats)
+        h0 = h0 + O.positional_conv(geo, base, h0)
+        exact = layers(geo, ref_sd, h0, "exact")
+        print(f"{DE.MODELS[model]} [{kind}], {h0.shape[0]} frames, {geo.num_layers} layers; error of the worst state against exact fp64 layers")
+        variants = [("f16x", None), ("bf16x3", None), ("f16m8", None), ("f16m6", None), ("f16", ("fc1", "fc2")), ("f16", None)]
+        if len(sys.argv) > 4:
+            variants = [(v, None) for v in sys.argv[4].split(",")]
+        for arith, sites in variants:
+            got = layers(geo, ref_sd, h0, arith) if sites is None else layers(geo, ref_sd, h0, arith, sites)
+            per = [float((a - b).abs().max() / max(1.0, float(b.abs().max()))) for a, b in zip(got, exact)]
+            L = len(per) - 1
+            tag = arith + ("" if sites is None else " on " + "+".join(sites))
+            print(f"  {tag:22s} state {L // 2}: {per[L // 2]:.2e}   state {L}: {per[L]:.2e}   worst {max(per):.2e}")
+            sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
