@@ -342,8 +342,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--max_len", type=int, default=80, help="tokens per text (roberta workloads)")
     ap.add_argument("--ssl_type", type=str, default="microsoft/wavlm-large")
-    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x", "f16", "f16q", "f16a", "f16x"])
-    ap.add_argument("--parity-mode", type=str, default="f16x,f16a,f16,fp32x",
+    ap.add_argument("--mode", type=str, default="bf16", choices=["bf16", "fp32x", "f16", "f16q", "f16a", "f16x", "f16m"])
+    ap.add_argument("--parity-mode", type=str, default="f16x,f16m,f16a,f16,fp32x",
                     help="numerics mode(s) of the parity records, comma separated: the first fills `parity_mode`, "
                          "the others `parity_mode_<name>`")
     ap.add_argument("--layers", type=int, default=0, help="debug: truncate the encoder (invalidates the metric)")
@@ -587,7 +587,8 @@ def main():
         gf_utt = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
         dtype_name = {"bf16": "bf16", "fp32x": "bf16x3 (bf16 hi + lo planes, 3 products)", "f16": "f16 (f16x3 stem)",
                       "f16q": "f16 (f16x3 stem and logit path)", "f16a": "f16 (f16x3 stem and attention block)",
-                      "f16x": "f16x3 (fp16 hi + lo planes, 3 products)"}
+                      "f16x": "f16x3 (fp16 hi + lo planes, 3 products)",
+                      "f16m": "f16 + block-scaled e4m3 cross terms (2 product-equivalents; f16x3 stem, attention, output projection)"}
         out = {
             "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract" if geo is C.WAVLM_LARGE and abs(args.seconds - 10) < 1e-6
                       else f"utterances/sec ({args.seconds:.0f} s @16 kHz) {geo.name} embed extract",
@@ -713,7 +714,7 @@ def main():
             first = [f"batch {j} utterance {a}" for j, a, _ in branches]     # first utterance of every branch
             ref = oracle_states(geo, sd, waves[0], whisper)               # CPU oracle on utterance 0 (full geometry, T frames)
             err_m = max(rel_err(hs_timed[0].utterance(0, l).cpu(), r) for l, r in enumerate(ref))
-            bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3, "f16q": 1e-3, "f16a": 1e-3, "f16x": 1e-3}[args.mode]
+            bound = {"bf16": 3e-2, "fp32x": 1e-3, "f16": 1e-3, "f16q": 1e-3, "f16a": 1e-3, "f16x": 1e-3, "f16m": 1e-3}[args.mode]
             verification.update({"weights": "seeded synthetic weights of the named geometry (no checkpoint can be fetched offline): every error "
                                             "below is on those; stress fixtures (LoRA-scaled queries, sharp attention, outlier channels) are in tests/",
                                  "timed_mode": args.mode, "timed_mode_max_rel_err_vs_oracle": float(f"{err_m:.3e}"),
@@ -722,6 +723,10 @@ def main():
             what = {"fp32x": "bf16 x3 split (hi*hi + lo*hi + hi*lo) everywhere",
                     "f16x": "the same 3-product split everywhere on fp16 hi + lo planes (22-bit operands instead of 16; the drivers' default since "
                             "round 4: <= 1.0e-4 on the full-depth stress cases of profiles/r04_depth_envelope.txt)",
+                    "f16m": "round 5: packed projection, FC1 and FC2 as fp16 main product + block-scaled e4m3 cross terms on "
+                            "v_mfma_scale_f32_16x16x128_f8f6f4 (x_hi w_hi + x_lo w_8 + x_8 w_lo: 2 product-equivalents instead of 3, operand error "
+                            "~2^-15); conv stem, attention and output projection on the fp16 hi + lo split (full-depth stress cases: "
+                            "profiles/r05_depth_envelope_f16m*.txt, <= 4.8e-4, inside fp32x's on every case)",
                     "f16": "fp32x conv stem (conv stack, projection, positional conv) + fp16 single-product encoder layers",
                     "f16a": "fp32x conv stem; packed QKV projection, attention (S = K Q^T, P V) and output projection on the 3-product "
                             "split over fp16 hi + lo planes; FC1 / FC2 (62 % of the layer FLOPs) single-product fp16",

@@ -29,6 +29,9 @@
 #ifndef SER_GEMM_PP
 #define SER_GEMM_PP 27        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile, 8 = the FP32X 128x128 tile, 16 = the FP32X 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
 #endif
+#ifndef SER_GEMM_SUPER
+#define SER_GEMM_SUPER 1      // 4 x 8 super-tile order of the blocks inside an XCD's run (see the kernel); 0 = row-major (A/B builds)
+#endif
 #include <stdlib.h>
 #include <stdio.h>
 #include <atomic>
@@ -125,7 +128,24 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         bid = base + (bid >> 3);
     }
-    const int mt = bid / ntn, nt = bid - mt * ntn;
+    // Tile order inside an XCD's run (round 5).  The blocks of one XCD start in id order on its 32 CUs, so 32 consecutive ids are resident
+    // together and share that XCD's 4 MiB L2.  Row-major ids make them ONE row of tiles when the grid is >= 32 tiles wide (FC1: one A panel,
+    // 32 weight panels: 1 + 32 x 1/2 = 17 panel fetches per K step for 32 tiles); as a 4 x 8 super-tile they fetch 4 + 8 x 1/2 = 8 -- the L2 -> LDS
+    // fill, which bounds these K loops, is served from L2 (~70 GB/s per CU) instead of the Infinity Cache (~33) for that much more of it.
+    // Needs ntn % 8 == 0 (otherwise the row-major order stays); the last, partial super-row keeps 8-wide groups of its own height.
+    int mt, nt;
+    if (SER_GEMM_SUPER && (ntn & 7) == 0 && ntn > 8) {
+        const int per_sr = 4 * ntn;                                   // tiles per full super-row
+        const int sr = bid / per_sr;
+        const int tt = bid - sr * per_sr;
+        const int h = (sr * 4 + 4 <= ntm) ? 4 : ntm - sr * 4;          // height of this super-row
+        const int sc = tt / (h * 8), j = tt - sc * (h * 8);
+        mt = sr * 4 + j / 8;
+        nt = sc * 8 + (j & 7);
+    } else {
+        mt = bid / ntn;
+        nt = bid - mt * ntn;
+    }
     const int g = blockIdx.y;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -185,6 +205,25 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         }
         char* dstA = lds + i_stage * STAGE + wave * 1024;        // stage = [A hi][A lo][W hi][W lo]
         char* dstW = dstA + NPL * A_BYTES;
+        if constexpr (M16) {
+            // source rows recomputed per DMA from (m0, n0, lane) instead of kept as LA + LW 64-bit pointers: those 16 registers, beside the 128
+            // accumulators of the 256x256 tile, spilled -- and a reload in this block waits vmcnt(0), i.e. for the DMAs just issued
+            const int coff = ((lane % CH) ^ (lane / CH)) * 8;    // BK = 64: the swizzle f(R) = R & 7 = the lane's row inside its 8-row piece
+#pragma unroll
+            for (int q = 0; q < LA; ++q) {
+                int m = m0 + (q * NW + wave) * RPP + lane / CH;
+                asm volatile("" : "+v"(m));                        // (opaque: keeps hipcc from hoisting the 64-bit row addresses out of the K loop again)
+                m = m < p.M ? m : p.M - 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(Abase + (int64_t)m * p.lda + coff + koffA), (lptr_t)(dstA + q * NW * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < LW; ++q) {
+                int n = n0 + (q * NW + wave) * RPP + lane / CH;
+                asm volatile("" : "+v"(n));
+                n = n < p.N ? n : p.N - 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wbase + (int64_t)n * p.K + coff + koffW), (lptr_t)(dstW + q * NW * 1024), 16, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
