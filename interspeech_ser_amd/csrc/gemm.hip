@@ -30,7 +30,7 @@
 #define SER_GEMM_PP 27        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile, 8 = the FP32X 128x128 tile, 16 = the FP32X 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
 #endif
 #ifndef SER_GEMM_SUPER
-#define SER_GEMM_SUPER 1      // 4 x 8 super-tile order of the blocks inside an XCD's run (see the kernel); 0 = row-major (A/B builds)
+#define SER_GEMM_SUPER 0      // 1 = 4 x 8 super-tile order of the blocks inside an XCD's run (see the kernel): FC1 alone 2 - 4 % faster, the step unchanged (profiles/r05_gemm_super_tile_ab.txt)
 #endif
 #include <stdlib.h>
 #include <stdio.h>
@@ -205,9 +205,11 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         }
         char* dstA = lds + i_stage * STAGE + wave * 1024;        // stage = [A hi][A lo][W hi][W lo]
         char* dstW = dstA + NPL * A_BYTES;
-        if constexpr (M16) {
-            // source rows recomputed per DMA from (m0, n0, lane) instead of kept as LA + LW 64-bit pointers: those 16 registers, beside the 128
-            // accumulators of the 256x256 tile, spilled -- and a reload in this block waits vmcnt(0), i.e. for the DMAs just issued
+        if constexpr (M16 && TM * TN >= 32) {
+            // 256x256 FP16M tile only: source rows recomputed per DMA from (m0, n0, lane) instead of kept as LA + LW 64-bit pointers: those 16
+            // registers, beside its 128 accumulators, spilled -- and a reload in this block waits vmcnt(0), i.e. for the DMAs just issued (196 ->
+            // 139 us on the packed projection).  The 256x128 tile has the registers and LOSES 15 % with the extra address arithmetic in front
+            // of every DMA (packed projection 122 -> 140 us, FC1 172 -> 202): it keeps the pointers.
             const int coff = ((lane % CH) ^ (lane / CH)) * 8;    // BK = 64: the swizzle f(R) = R & 7 = the lane's row inside its 8-row piece
 #pragma unroll
             for (int q = 0; q < LA; ++q) {
@@ -1153,8 +1155,9 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     }
     if (a->mode == SER_MODE_FP16M) {
         // the single-plane tiles walked twice per K tile (H unit, E unit): 256x128 on a three-stage ring from 100 tiles up, 128x128 on four waves
-        // below that.  The 256x256 form (two stages of 64 KiB: one unit in flight) is built and exact but SLOWER at M = 7 984 -- packed projection
-        // 196 us against 126 us on 256x128, FC1 212 against 181 (profiles/r05_gemm_f16m_bench.txt) -- so only tile_cfg = 3 selects it
+        // below that.  The 256x256 form (two stages of 64 KiB: one unit in flight) is built and exact but not faster at M = 7 984 -- packed projection
+        // 139 us against 122 us on 256x128, FC1 162 against 169 - 175, FC2 206 against 130 (profiles/r05_gemm_f16m_bench.txt) -- so only
+        // tile_cfg = 3 selects it
         const long t256sq = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
         const long t256x128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128);
         static const long m_sq_min = SER_KNOB("SER_GEMM_M16_SQ_MIN", 1L << 30), m_256_min = SER_KNOB("SER_GEMM_M16_256_MIN", 100);
