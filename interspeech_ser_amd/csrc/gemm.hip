@@ -29,6 +29,15 @@
 #ifndef SER_GEMM_PP
 #define SER_GEMM_PP 27        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile, 8 = the FP32X 128x128 tile, 16 = the FP32X 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
 #endif
+#ifndef SER_M16_READS_FIRST
+#define SER_M16_READS_FIRST 1  // FP16M ping-pong loop: fragment reads of a unit are issued before its DMAs (0: DMAs first, like the other tiles)
+#endif
+#ifndef SER_M16_PRIO
+#define SER_M16_PRIO 1        // FP16M ping-pong loop: 1 = s_setprio 1 around the MFMA phase (as the other tiles), 0 = none, 2 = around the read / DMA-issue phase
+#endif
+#ifndef SER_WHATIF
+#define SER_WHATIF 0          // diagnostic builds only (tools/ab): 1 = no MFMAs, 2 = no DMA, 4 = no fragment reads after the first K tile of the FP16M loop
+#endif
 #ifndef SER_GEMM_SUPER
 #define SER_GEMM_SUPER 0      // 1 = 4 x 8 super-tile order of the blocks inside an XCD's run (see the kernel): FC1 alone 2 - 4 % faster, the step unchanged (profiles/r05_gemm_super_tile_ab.txt)
 #endif
@@ -44,6 +53,24 @@ __device__ unsigned long long* ser_gemm_dbg_dev = nullptr;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA wave instruction in its scalar-base form: 64 lanes x BYTES from (uniform base + the lane's 32-bit offset) to LDS bytes
+// [lds_addr, lds_addr + 64 * BYTES), lane-linear.  M0 carries the LDS address; nothing else in this library uses M0.
+// a pointer the compiler may hold in VGPRs although every lane has the same value -> SGPR pair (the "s" asm constraint is not enforced
+// for 64-bit operands: without this the -DSER_GEMM_DBG build handed the instruction a VGPR pair)
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+template <int BYTES>
+__device__ __forceinline__ void dma_lds(const void* ubase, uint32_t voff, uint32_t lds_addr) {
+    static_assert(BYTES == 16 || BYTES == 4, "dwordx4 or dword");
+    if constexpr (BYTES == 16)
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(ubase), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(ubase), "s"(lds_addr) : "memory");
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -152,10 +179,21 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     const unsigned short* Abase = (const unsigned short*)p.A + (int64_t)g * p.a_group_stride;
     const unsigned short* Wbase = (const unsigned short*)p.W + (int64_t)g * p.w_group_stride;
 
-    // ---- per-lane DMA source rows -----------------------------------------------------------
+    // ---- per-lane DMA sources: a 32-bit byte offset from a UNIFORM tile base ---------------------
+    // (round 5) global_load_lds is issued in its scalar-base form -- global_load_lds_dwordx4 v_offset, s[base:base+1] -- from inline asm:
+    // the K offset of a tile, the plane and the group go into the 64-bit SGPR base with scalar adds, the lane contributes the 32-bit
+    // offset of its row / chunk inside the block's tile and there is NO vector instruction in front of a DMA.  With the builtin hipcc
+    // keeps 64-bit VGPR pointers and emits two v_lshl_add_u64 per DMA (it never selects the scalar-base form); those vector instructions
+    // compete for the SIMD's issue slots with the partner wave's MFMAs -- the DMA-issuing phase of one wave and the MFMA phase of the other
+    // were not overlapping (FP16M FC2 at M = 7 984: MFMAs alone 82 us, DMA + reads alone 79 us, together 127 us; tools/ab what-if builds).
+    // Offsets are relative to the tile's first row (a_rowoff maps must be non-decreasing in m -- every map the hosts build is), so they
+    // stay far below 2^32 whatever the tensor size.
     const int prow = lane / CH, ppos = lane % CH;
-    const unsigned short* aptr[LA];
-    const unsigned short* wptr[LW];
+    uint32_t aoff[LA], woff[LW];
+    const int m0c = m0 < p.M ? m0 : p.M - 1;
+    const int64_t arow0 = p.a_rowoff ? (int64_t)p.a_rowoff[m0c] * 8 : (int64_t)m0c * p.lda;      // uniform
+    const char* const Atile = uniform_ptr(Abase + arow0);
+    const char* const Wtile = uniform_ptr(Wbase + (int64_t)n0 * p.K);
 #pragma unroll
     for (int q = 0; q < LA; ++q) {
         const int R = (q * NW + wave) * RPP + prow;                               // LDS row this lane fills
@@ -164,7 +202,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         int m = m0 + R;
         m = m < p.M ? m : p.M - 1;
         const int64_t arow = p.a_rowoff ? (int64_t)p.a_rowoff[m] * 8 : (int64_t)m * p.lda;
-        aptr[q] = Abase + arow + c * 8;
+        aoff[q] = (uint32_t)((arow - arow0 + c * 8) * 2);
     }
 #pragma unroll
     for (int q = 0; q < LW; ++q) {
@@ -173,8 +211,9 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         const int c = ppos ^ f;
         int n = n0 + R;
         n = n < p.N ? n : p.N - 1;
-        wptr[q] = Wbase + (int64_t)n * p.K + c * 8;
+        woff[q] = (uint32_t)(((int64_t)(n - n0) * p.K + c * 8) * 2);
     }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
 
     const int nk = p.K / BK;
     const int total = M16 ? 2 * nk : nk;          // FP16M: two ring units per K tile
@@ -184,13 +223,17 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     // BM + BN words (A rows first), 4 bytes per lane; with more waves than 64-row chunks the surplus waves repeat a chunk (same bytes,
     // same place), so every wave issues the same number of DMAs and the counted waits stay uniform
     unsigned char* const scl = (unsigned char*)(lds + ST * STAGE + (LNEPI ? 0 : BM * 8));     // [ST][SCW] words, behind the row statistics
-    const uint32_t* sc_src = nullptr;
-    int64_t sc_step = 0;
     const int sc_chunk = M16 ? (wave % (SCW / 64)) : 0;
+    const bool sc_is_a = sc_chunk * 64 < BM;                                     // wave-uniform: this wave's 64 words are A rows / W rows
+    const char* const sc_base = uniform_ptr(sc_is_a ? p.a_scale : p.w_scale);
+    const int64_t sc_step = (sc_is_a ? p.a_scale_ld : p.w_scale_ld) * 4;       // bytes between K tiles
+    uint32_t sc_off = 0;
     if constexpr (M16) {
         const int r = sc_chunk * 64 + lane;
-        if (r < BM) { int m = m0 + r; m = m < p.M ? m : p.M - 1; sc_src = p.a_scale + m; sc_step = p.a_scale_ld; }
-        else { int n = n0 + r - BM; n = n < p.N ? n : p.N - 1; sc_src = p.w_scale + n; sc_step = p.w_scale_ld; }
+        int i = sc_is_a ? m0 + r : n0 + r - BM;
+        const int lim = sc_is_a ? p.M : p.N;
+        i = i < lim ? i : lim - 1;
+        sc_off = (uint32_t)i * 4u;
     }
     int i_kk = 0, i_cc = 0, i_cj = 0, i_stage = 0;                               // issue-side scalar state
     auto issue = [&]() {
@@ -199,43 +242,18 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         if constexpr (M16) {                                     // unit i_kk: K tile i_kk / 2, plane i_kk & 1 (same byte offsets in both planes)
             koffA = (int64_t)(i_kk >> 1) * BK + (i_kk & 1) * p.a_plane_stride;
             koffW = (int64_t)(i_kk >> 1) * BK + (i_kk & 1) * p.w_plane_stride;
-            if (i_kk & 1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(sc_src + (int64_t)(i_kk >> 1) * sc_step),
-                                                 (lptr_t)(scl + (i_stage * SCW + sc_chunk * 64) * 4), 4, 0, 0);
+            if (i_kk & 1) dma_lds<4>(sc_base + (int64_t)(i_kk >> 1) * sc_step, sc_off, lds0 + (uint32_t)(ST * STAGE + (LNEPI ? 0 : BM * 8) + (i_stage * SCW + sc_chunk * 64) * 4));
         }
-        char* dstA = lds + i_stage * STAGE + wave * 1024;        // stage = [A hi][A lo][W hi][W lo]
-        char* dstW = dstA + NPL * A_BYTES;
-        if constexpr (M16 && TM * TN >= 32) {
-            // 256x256 FP16M tile only: source rows recomputed per DMA from (m0, n0, lane) instead of kept as LA + LW 64-bit pointers: those 16
-            // registers, beside its 128 accumulators, spilled -- and a reload in this block waits vmcnt(0), i.e. for the DMAs just issued (196 ->
-            // 139 us on the packed projection).  The 256x128 tile has the registers and LOSES 15 % with the extra address arithmetic in front
-            // of every DMA (packed projection 122 -> 140 us, FC1 172 -> 202): it keeps the pointers.
-            const int coff = ((lane % CH) ^ (lane / CH)) * 8;    // BK = 64: the swizzle f(R) = R & 7 = the lane's row inside its 8-row piece
-#pragma unroll
-            for (int q = 0; q < LA; ++q) {
-                int m = m0 + (q * NW + wave) * RPP + lane / CH;
-                asm volatile("" : "+v"(m));                        // (opaque: keeps hipcc from hoisting the 64-bit row addresses out of the K loop again)
-                m = m < p.M ? m : p.M - 1;
-                __builtin_amdgcn_global_load_lds((gptr_t)(Abase + (int64_t)m * p.lda + coff + koffA), (lptr_t)(dstA + q * NW * 1024), 16, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < LW; ++q) {
-                int n = n0 + (q * NW + wave) * RPP + lane / CH;
-                asm volatile("" : "+v"(n));
-                n = n < p.N ? n : p.N - 1;
-                __builtin_amdgcn_global_load_lds((gptr_t)(Wbase + (int64_t)n * p.K + coff + koffW), (lptr_t)(dstW + q * NW * 1024), 16, 0, 0);
-            }
-        } else
+        const uint32_t dstA = lds0 + i_stage * STAGE + wave * 1024;   // stage = [A hi][A lo][W hi][W lo]
+        const uint32_t dstW = dstA + NPL * A_BYTES;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
+            const char* ua = Atile + (koffA + pl * p.a_plane_stride) * 2;
+            const char* uw = Wtile + (koffW + pl * p.w_plane_stride) * 2;
 #pragma unroll
-            for (int q = 0; q < LA; ++q)
-                __builtin_amdgcn_global_load_lds((gptr_t)(aptr[q] + koffA + pl * p.a_plane_stride),
-                                                 (lptr_t)(dstA + pl * A_BYTES + q * NW * 1024), 16, 0, 0);
+            for (int q = 0; q < LA; ++q) dma_lds<16>(ua, aoff[q], dstA + pl * A_BYTES + q * NW * 1024);
 #pragma unroll
-            for (int q = 0; q < LW; ++q)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wptr[q] + koffW + pl * p.w_plane_stride),
-                                                 (lptr_t)(dstW + pl * W_BYTES + q * NW * 1024), 16, 0, 0);
+            for (int q = 0; q < LW; ++q) dma_lds<16>(uw, woff[q], dstW + pl * W_BYTES + q * NW * 1024);
         }
         ++i_kk; ++i_cc;
         if (i_cc == tpc) { i_cc = 0; ++i_cj; }
@@ -532,7 +550,22 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             auto unit = [&](int kt, auto etag) {
                 constexpr bool EU = decltype(etag)::value;
                 const bool more = kt + ST - 1 < total;
+#ifdef SER_GEMM_DBG
+                unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // phase stamps of units 8 .. 15 of one block (tools/gemm_m16_phases.py)
+                const bool stamp = ser_gemm_dbg_dev && blockIdx.x == 40 && lane == 0 && kt >= 8 && kt < 16;
+#define SER_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (stamp) stp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+                SER_STAMP(0);
+#else
+#define SER_STAMP(i) do { } while (0)
+#endif
+#if !SER_M16_READS_FIRST
+#if SER_WHATIF & 2
+                if (more && kt < 2) issue();                       // what-if: the ring is filled once, then no more DMA (wrong results)
+#else
                 if (more) issue();
+#endif
+#endif
+                SER_STAMP(1);                                      // DMAs of unit kt + ST - 1 issued
                 const char* sb = lds + stage * STAGE;
                 const unsigned char* scb = scl + stage * SCW * 4;
                 stage = (stage + 1 == ST) ? 0 : stage + 1;
@@ -543,22 +576,56 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     bf16x8 af[EU ? 1 : SPM][EU ? 1 : TM], wf[EU ? 1 : SPM][EU ? 1 : TN];
                     i32x8 a8[EU ? TMP : 1], w8[EU ? TN : 1];
                     int sa[EU ? TMP : 1], sw[EU ? TN : 1];
+#if SER_WHATIF & 4
+                    if (kt < 2) {                                  // what-if: fragments read for the first K tile only (wrong results)
+#endif
                     if constexpr (!EU) h_phase_reads(sb, ph, af, wf);
                     else e_phase_reads(sb, scb, ph, a8, w8, sa, sw);
+#if SER_WHATIF & 4
+                    }
+#endif
+#if SER_M16_READS_FIRST
+                    // the DMAs of unit kt + ST - 1 go out BEHIND the fragment reads of the unit's first phase: the LDS latency of those reads
+                    // passes under the ~350 cycles the DMA issue holds the wave (the stage they refill was last read one unit ago)
+                    if (ph == 0 && more) { __builtin_amdgcn_sched_barrier(0); issue(); }
+#endif
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ph == 0) SER_STAMP(2);                      // fragments in registers
                     if (ph == NPH - 1 && late) wait_landed(more, kt + ST - 1);
+                    if (ph == 0) SER_STAMP(3);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+                    if (ph == 0) SER_STAMP(4);                      // past the barrier in front of the MFMA phase
+#if SER_M16_PRIO == 1
                     __builtin_amdgcn_s_setprio(1);
+#elif SER_M16_PRIO == 2
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+#if SER_WHATIF & 1
+                    if (kt < 2) {                                  // what-if: matrix instructions for the first K tile only (wrong results)
+#endif
                     if constexpr (!EU) h_phase_mfma(af, wf);
                     else e_phase_mfma(ph, a8, w8, sa, sw);
+#if SER_WHATIF & 1
+                    }
+#endif
+#if SER_M16_PRIO == 1
                     __builtin_amdgcn_s_setprio(0);
+#elif SER_M16_PRIO == 2
+                    __builtin_amdgcn_s_setprio(1);                 // the read / DMA-issue phase that follows runs at priority
+#endif
+                    if (ph == 0) SER_STAMP(5);                      // MFMAs issued
                     if (ph == NPH - 1 && !late) wait_landed(more, kt + ST - 1);
+                    if (ph == 0) SER_STAMP(6);
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(ph == NPH - 1 && last && late)) __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+                    if (ph == 0) SER_STAMP(7);
                 }
+#ifdef SER_GEMM_DBG
+                if (stamp) for (int i = 0; i < 8; ++i) ser_gemm_dbg_dev[262144 + ((wave * 8 + (kt - 8)) * 8 + i)] = stp[i];
+#endif
             };
             for (int kt = 0; kt < total; kt += 2) {
                 unit(kt, std::false_type{});
