@@ -183,10 +183,11 @@ typedef struct ser_gemm_args {
     const uint32_t* a_scale;  int64_t a_scale_ld;
     const uint32_t* w_scale;  int64_t w_scale_ld;
     uint32_t*       out_scale; int64_t out_scale_ld;
-    /* fp16 range guard (ABI 13): when not NULL, the launch ORs 1 into *range_flag if any value it rounds to an fp16 operand plane
-     * (out_act in the FP16 / FP16X / FP16M formats) exceeds 65504 in magnitude BEFORE the saturating conversion -- the host reads the
-     * word back with the batch's features and fails that batch's files instead of writing clipped ones (preprocess_speech.py:46,72-73:
-     * a bad file is a printed failure, never silent garbage). */
+    /* fp16 range guard (ABI 13): when not NULL, the launch ORs into *range_flag bit 0 if any value it rounds to an fp16 operand plane
+     * (out_act in the FP16 / FP16X / FP16M formats) exceeds 65504 in magnitude (or is a NaN) BEFORE the saturating conversion, bit 1 if
+     * one exceeds half that -- the host reads the word back with the batch's features and fails that batch's files instead of writing
+     * clipped ones (preprocess_speech.py:46,72-73: a bad file is a printed failure, never silent garbage).  ser_layernorm_v,
+     * ser_row_center_v, ser_wave_frames_v, ser_pack_act_v and ser_pack_f16m take the same word. */
     uint32_t*       range_flag;
 } ser_gemm_args;
 int ser_gemm(const ser_gemm_args* args, void* stream);
@@ -355,7 +356,9 @@ typedef struct ser_layernorm_args {
     const float* x; int64_t ldx; const float* g; const float* b; float eps; int32_t gelu;
     float* out_f32; int64_t ldo_f32; void* out_act; int64_t ldo_act; int64_t out_plane_stride;
     int32_t mode, rows, D, reserved0;
+    uint32_t* range_flag;                           /* fp16 range guard, may be NULL (ABI 13) */
 } ser_layernorm_args;
+int ser_layernorm_v(const ser_layernorm_args* args, void* stream);
 
 typedef struct ser_row_center_args {
     const float* x; int64_t ldx; void* out_act; int64_t ldo_act; int64_t out_plane_stride;
@@ -371,12 +374,16 @@ typedef struct ser_logmel_args {
 
 typedef struct ser_pack_act_args {
     const float* x; void* out; int64_t ldo; int64_t out_plane_stride; int32_t B, C, T, halo, mode, reserved0;
+    uint32_t* range_flag;                           /* fp16 range guard, may be NULL (ABI 13) */
 } ser_pack_act_args;
+int ser_pack_act_v(const ser_pack_act_args* args, void* stream);
 
 typedef struct ser_wave_frames_args {
     const float* wav; const int64_t* sample_offs; const int32_t* frame_offs; int32_t B, k, stride, mode;
     void* out; int64_t out_plane_stride; void* work; int32_t total_rows, reserved0;
+    uint32_t* range_flag;                           /* fp16 range guard, may be NULL (ABI 13) */
 } ser_wave_frames_args;
+int ser_wave_frames_v(const ser_wave_frames_args* args, void* stream);
 
 #define SER_OP_GEMM 1
 #define SER_OP_ATTENTION 2

@@ -78,6 +78,7 @@ class LayerNormArgs(C.Structure):
         ("x", c_void_p), ("ldx", c_i64), ("g", c_void_p), ("b", c_void_p), ("eps", c_float), ("gelu", C.c_int32),
         ("out_f32", c_void_p), ("ldo_f32", c_i64), ("out_act", c_void_p), ("ldo_act", c_i64), ("out_plane_stride", c_i64),
         ("mode", C.c_int32), ("rows", C.c_int32), ("D", C.c_int32), ("reserved0", C.c_int32),
+        ("range_flag", c_void_p),
     ]
 
 
@@ -88,6 +89,7 @@ class WaveFramesArgs(C.Structure):
         ("B", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("mode", C.c_int32),
         ("out", c_void_p), ("out_plane_stride", c_i64), ("work", c_void_p),
         ("total_rows", C.c_int32), ("reserved0", C.c_int32),
+        ("range_flag", c_void_p),
     ]
 
 
@@ -110,7 +112,8 @@ class LogmelArgs(C.Structure):
 class PackActArgs(C.Structure):
     """Mirror of ``ser_pack_act_args``."""
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("ldo", c_i64), ("out_plane_stride", c_i64),
-                ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("halo", C.c_int32), ("mode", C.c_int32), ("reserved0", C.c_int32)]
+                ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("halo", C.c_int32), ("mode", C.c_int32), ("reserved0", C.c_int32),
+                ("range_flag", c_void_p)]
 
 
 class _CmdUnion(C.Union):
@@ -141,6 +144,9 @@ _SIGNATURES = {
                               c_i64, c_int, c_int, c_int, c_void_p]),
     "ser_row_center": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ser_row_center_v": (c_int, [c_void_p, c_void_p]),
+    "ser_layernorm_v": (c_int, [c_void_p, c_void_p]),
+    "ser_wave_frames_v": (c_int, [c_void_p, c_void_p]),
+    "ser_pack_act_v": (c_int, [c_void_p, c_void_p]),
     "ser_pack_f16m": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "ser_wavlm_bias_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ser_wavlm_gate": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

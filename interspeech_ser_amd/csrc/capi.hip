@@ -41,15 +41,11 @@ extern "C" int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void*
                 break;
             }
             case SER_OP_LAYERNORM: {
-                const ser_layernorm_args& a = c.u.layernorm;
-                rc = ser_layernorm(a.x, a.ldx, a.g, a.b, a.eps, a.gelu, a.out_f32, a.ldo_f32, a.out_act, a.ldo_act,
-                                   a.out_plane_stride, a.mode, a.rows, a.D, stream);
+                rc = ser_layernorm_v(&c.u.layernorm, stream);
                 break;
             }
             case SER_OP_WAVE_FRAMES: {
-                const ser_wave_frames_args& a = c.u.wave_frames;
-                rc = ser_wave_frames(a.wav, a.sample_offs, a.frame_offs, a.B, a.k, a.stride, a.out, a.out_plane_stride, a.mode,
-                                     a.work, a.total_rows, stream);
+                rc = ser_wave_frames_v(&c.u.wave_frames, stream);
                 break;
             }
             case SER_OP_ROW_CENTER: {
@@ -62,8 +58,7 @@ extern "C" int ser_run(const ser_cmd* cmds, int32_t n, int32_t* failed_at, void*
                 break;
             }
             case SER_OP_PACK_ACT: {
-                const ser_pack_act_args& a = c.u.pack_act;
-                rc = ser_pack_act(a.x, a.B, a.C, a.T, a.halo, a.out, a.ldo, a.out_plane_stride, a.mode, stream);
+                rc = ser_pack_act_v(&c.u.pack_act, stream);
                 break;
             }
             default:

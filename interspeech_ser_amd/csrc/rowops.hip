@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict
 template <int MODE>
 __global__ __launch_bounds__(256) void wave_frames_kernel(const float* __restrict__ wav, const int64_t* __restrict__ soffs,
                                                           const int32_t* __restrict__ foffs, const double* __restrict__ part,
-                                                          unsigned short* __restrict__ out, int64_t plane, int k, int stride) {
+                                                          unsigned short* __restrict__ out, int64_t plane, int k, int stride, uint32_t* __restrict__ rflag) {
     __shared__ float stat[2];
+    float ramax = 0.f;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int64_t s0 = soffs[b], n = soffs[b + 1] - s0;
     if (tid < 64) {
@@ -104,12 +105,19 @@ __global__ __launch_bounds__(256) void wave_frames_kernel(const float* __restric
         unsigned short* dst = out + (int64_t)(row_begin + t) * 64 + c * 8;
         store_act4<MODE>(dst, plane, v[0], v[1], v[2], v[3]);
         store_act4<MODE>(dst + 4, plane, v[4], v[5], v[6], v[7]);
+        if constexpr (mode_traits<MODE>::f16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ramax = fmaxf(ramax, fabsf(v[i]));
+        }
     }
+    if constexpr (mode_traits<MODE>::f16) range_report(rflag, ramax);
 }
 
-extern "C" int ser_wave_frames(const float* wav, const int64_t* sample_offs, const int32_t* frame_offs, int B, int k,
-                               int stride, void* out, int64_t out_plane_stride, int mode, void* work, int total_rows,
-                               void* stream) {
+extern "C" int ser_wave_frames_v(const ser_wave_frames_args* a, void* stream) {
+    if (!a) return ser_fail(-1, "ser_wave_frames: null pointer");
+    const float* wav = a->wav; const int64_t* sample_offs = a->sample_offs; const int32_t* frame_offs = a->frame_offs;
+    const int B = a->B, k = a->k, stride = a->stride, mode = a->mode, total_rows = a->total_rows;
+    void* out = a->out; const int64_t out_plane_stride = a->out_plane_stride; void* work = a->work;
     if (!wav || !sample_offs || !frame_offs || !out || !work) return ser_fail(-1, "ser_wave_frames: null pointer");
     if (B <= 0 || k < 1 || k > 64 || stride < 1 || total_rows <= 0) return ser_fail(-2, "ser_wave_frames: bad B/k/stride/rows");
     if (mode != SER_MODE_BF16 && mode != SER_MODE_FP32X && mode != SER_MODE_FP16X) return ser_fail(-3, "ser_wave_frames: bad mode");
@@ -118,16 +126,22 @@ extern "C" int ser_wave_frames(const float* wav, const int64_t* sample_offs, con
     int blocks = ((total_rows + B - 1) / B + 31) / 32;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    if (mode == SER_MODE_FP32X)
-        hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_FP32X>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
-                           (const double*)work, (unsigned short*)out, out_plane_stride, k, stride);
-    else if (mode == SER_MODE_FP16X)
-        hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_FP16X>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
-                           (const double*)work, (unsigned short*)out, out_plane_stride, k, stride);
-    else
-        hipLaunchKernelGGL(wave_frames_kernel<SER_MODE_BF16>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs,
-                           (const double*)work, (unsigned short*)out, out_plane_stride, k, stride);
+#define SER_WF(M_) hipLaunchKernelGGL(wave_frames_kernel<M_>, dim3(blocks, B), dim3(256), 0, s, wav, sample_offs, frame_offs, \
+                                      (const double*)work, (unsigned short*)out, out_plane_stride, k, stride, a->range_flag)
+    if (mode == SER_MODE_FP32X) SER_WF(SER_MODE_FP32X);
+    else if (mode == SER_MODE_FP16X) SER_WF(SER_MODE_FP16X);
+    else SER_WF(SER_MODE_BF16);
+#undef SER_WF
     return ser_check_launch("ser_wave_frames");
+}
+
+extern "C" int ser_wave_frames(const float* wav, const int64_t* sample_offs, const int32_t* frame_offs, int B, int k,
+                               int stride, void* out, int64_t out_plane_stride, int mode, void* work, int total_rows,
+                               void* stream) {
+    ser_wave_frames_args a = {};
+    a.wav = wav; a.sample_offs = sample_offs; a.frame_offs = frame_offs; a.B = B; a.k = k; a.stride = stride; a.mode = mode;
+    a.out = out; a.out_plane_stride = out_plane_stride; a.work = work; a.total_rows = total_rows;
+    return ser_wave_frames_v(&a, stream);
 }
 
 // ------------------------------------------------------------------------------- K2
@@ -263,13 +277,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         float eps, int gelu, float* __restrict__ of, int64_t ldof,
                                                         unsigned short* __restrict__ oa, int64_t ldoa, int64_t plane,
-                                                        int rows, int D) {
+                                                        int rows, int D, uint32_t* __restrict__ rflag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (int64_t)row * ldx;
     f32x4 v[8];
-    float s = 0.f;
+    float s = 0.f, ramax = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = i * 256 + lane * 4;
@@ -300,31 +314,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
             if (of) *(f32x4*)(of + (int64_t)row * ldof + c) = y;
             if (oa) store_act4<MODE>(oa + (int64_t)row * ldoa + c, plane, y[0], y[1], y[2], y[3]);
+            if constexpr (mode_traits<MODE>::f16) { if (oa) ramax = fmaxf(ramax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])))); }
         }
     }
+    if constexpr (mode_traits<MODE>::f16) range_report(rflag, ramax);
+}
+
+extern "C" int ser_layernorm_v(const ser_layernorm_args* a, void* stream) {
+    if (!a) return ser_fail(-1, "ser_layernorm: null pointer");
+    const float* x = a->x; const int64_t ldx = a->ldx, ldo_f32 = a->ldo_f32, ldo_act = a->ldo_act, out_plane_stride = a->out_plane_stride;
+    const float* g = a->g; const float* b = a->b; const float eps = a->eps; const int gelu = a->gelu, mode = a->mode, rows = a->rows, D = a->D;
+    float* out_f32 = a->out_f32; void* out_act = a->out_act;
+    if (!x || !g || !b || (!out_f32 && !out_act)) return ser_fail(-1, "ser_layernorm: null pointer");
+    if (D % 4 || D > 2048 || D <= 0 || rows <= 0) return ser_fail(-2, "ser_layernorm: D=%d rows=%d unsupported", D, rows);
+    if ((ldx % 4) || (out_f32 && ldo_f32 % 4) || (out_act && ldo_act % 4)) return ser_fail(-3, "ser_layernorm: pitches must be multiples of 4");
+    dim3 grid((rows + 3) / 4), block(256);
+#define SER_LN(M_) hipLaunchKernelGGL(layernorm_kernel<M_>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu, out_f32, ldo_f32, \
+                                      (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D, a->range_flag)
+    if (mode == SER_MODE_FP32X) SER_LN(SER_MODE_FP32X);
+    else if (mode == SER_MODE_BF16) SER_LN(SER_MODE_BF16);
+    else if (mode == SER_MODE_FP16) SER_LN(SER_MODE_FP16);
+    else if (mode == SER_MODE_FP16X) SER_LN(SER_MODE_FP16X);
+    else return ser_fail(-4, "ser_layernorm: bad mode %d", mode);
+#undef SER_LN
+    return ser_check_launch("ser_layernorm");
 }
 
 extern "C" int ser_layernorm(const float* x, int64_t ldx, const float* g, const float* b, float eps, int gelu,
                              float* out_f32, int64_t ldo_f32, void* out_act, int64_t ldo_act,
                              int64_t out_plane_stride, int mode, int rows, int D, void* stream) {
-    if (!x || !g || !b || (!out_f32 && !out_act)) return ser_fail(-1, "ser_layernorm: null pointer");
-    if (D % 4 || D > 2048 || D <= 0 || rows <= 0) return ser_fail(-2, "ser_layernorm: D=%d rows=%d unsupported", D, rows);
-    if ((ldx % 4) || (out_f32 && ldo_f32 % 4) || (out_act && ldo_act % 4)) return ser_fail(-3, "ser_layernorm: pitches must be multiples of 4");
-    dim3 grid((rows + 3) / 4), block(256);
-    if (mode == SER_MODE_FP32X)
-        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
-                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
-    else if (mode == SER_MODE_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
-                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
-    else if (mode == SER_MODE_FP16)
-        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_FP16>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
-                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
-    else if (mode == SER_MODE_FP16X)
-        hipLaunchKernelGGL(layernorm_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, ldx, g, b, eps, gelu,
-                           out_f32, ldo_f32, (unsigned short*)out_act, ldo_act, out_plane_stride, rows, D);
-    else return ser_fail(-4, "ser_layernorm: bad mode %d", mode);
-    return ser_check_launch("ser_layernorm");
+    ser_layernorm_args a = {};
+    a.x = x; a.ldx = ldx; a.g = g; a.b = b; a.eps = eps; a.gelu = gelu; a.out_f32 = out_f32; a.ldo_f32 = ldo_f32; a.out_act = out_act;
+    a.ldo_act = ldo_act; a.out_plane_stride = out_plane_stride; a.mode = mode; a.rows = rows; a.D = D;
+    return ser_layernorm_v(&a, stream);
 }
 
 // ----------------------------------------------------------------- centred operand copy
@@ -655,7 +677,7 @@ extern "C" int ser_split_bf16(const float* x, void* out, int64_t plane_stride, i
 // utterance b occupies rows b*(T+2*halo) .. ; rows [halo, halo+T) carry data.
 template <int MODE>
 __global__ void pack_act_kernel(const float* __restrict__ x, int B, int C, int T, int halo,
-                                unsigned short* __restrict__ o, int64_t ldo, int64_t plane) {
+                                unsigned short* __restrict__ o, int64_t ldo, int64_t plane, uint32_t* __restrict__ rflag) {
     const int Tp = T + 2 * halo;
     const int64_t total = (int64_t)B * Tp * (C / 4);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -671,23 +693,30 @@ __global__ void pack_act_kernel(const float* __restrict__ x, int B, int C, int T
         for (int j = 0; j < 4; ++j) v[j] = x[((int64_t)b * C + cg * 4 + j) * T + t];
     }
     store_act4<MODE>(o + ((int64_t)b * Tp + tp) * ldo + cg * 4, plane, v[0], v[1], v[2], v[3]);
+    if constexpr (mode_traits<MODE>::f16) range_report(rflag, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+}
+
+extern "C" int ser_pack_act_v(const ser_pack_act_args* a, void* stream) {
+    if (!a) return ser_fail(-1, "ser_pack_act: bad arguments");
+    const float* x = a->x; void* out = a->out; const int B = a->B, C = a->C, T = a->T, halo = a->halo, mode = a->mode;
+    const int64_t ldo = a->ldo, out_plane_stride = a->out_plane_stride;
+    if (!x || !out || B <= 0 || C % 4 || T <= 0 || halo < 0) return ser_fail(-1, "ser_pack_act: bad arguments");
+    const int64_t total = (int64_t)B * (T + 2 * halo) * (C / 4);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define SER_PA(M_) hipLaunchKernelGGL(pack_act_kernel<M_>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo, (unsigned short*)out, ldo, \
+                                      out_plane_stride, a->range_flag)
+    if (mode == SER_MODE_FP32X) SER_PA(SER_MODE_FP32X);
+    else if (mode == SER_MODE_FP16X) SER_PA(SER_MODE_FP16X);
+    else SER_PA(SER_MODE_BF16);
+#undef SER_PA
+    return ser_check_launch("ser_pack_act");
 }
 
 extern "C" int ser_pack_act(const float* x, int B, int C, int T, int halo, void* out, int64_t ldo,
                             int64_t out_plane_stride, int mode, void* stream) {
-    if (!x || !out || B <= 0 || C % 4 || T <= 0 || halo < 0) return ser_fail(-1, "ser_pack_act: bad arguments");
-    const int64_t total = (int64_t)B * (T + 2 * halo) * (C / 4);
-    dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (mode == SER_MODE_FP32X)
-        hipLaunchKernelGGL(pack_act_kernel<SER_MODE_FP32X>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
-                           (unsigned short*)out, ldo, out_plane_stride);
-    else if (mode == SER_MODE_FP16X)
-        hipLaunchKernelGGL(pack_act_kernel<SER_MODE_FP16X>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
-                           (unsigned short*)out, ldo, out_plane_stride);
-    else
-        hipLaunchKernelGGL(pack_act_kernel<SER_MODE_BF16>, grid, block, 0, (hipStream_t)stream, x, B, C, T, halo,
-                           (unsigned short*)out, ldo, out_plane_stride);
-    return ser_check_launch("ser_pack_act");
+    ser_pack_act_args a = {};
+    a.x = x; a.out = out; a.ldo = ldo; a.out_plane_stride = out_plane_stride; a.B = B; a.C = C; a.T = T; a.halo = halo; a.mode = mode;
+    return ser_pack_act_v(&a, stream);
 }
 
 // ------------------------------------------------------------------ SER_MODE_FP16M packing

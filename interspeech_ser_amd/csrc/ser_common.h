@@ -389,6 +389,8 @@ __device__ __forceinline__ float mx_store_row(const float (&v)[VPL], bool ok, un
     }
     return amax_lane;
 }
+// fp16 range guard (ser_hip.h range_flag): bit 0 = a value beyond +-65504 (or a NaN) was rounded to an fp16 operand plane (it saturated),
+// bit 1 = a value beyond half that range was.  One rare atomic per lane that saw such a value; nothing otherwise.
 __device__ __forceinline__ void range_report(uint32_t* flag, float amax) {
-    if (flag && !(amax <= SER_F16_MAX)) atomicOr(flag, 1u);                           // NaN reports too
+    if (flag && !(amax <= 0.5f * SER_F16_MAX)) atomicOr(flag, !(amax <= SER_F16_MAX) ? 3u : 2u);
 }

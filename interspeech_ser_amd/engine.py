@@ -210,10 +210,26 @@ class HiddenStates:
     def frames(self, b: int) -> int:
         return self.frame_offs[b + 1] - self.frame_offs[b]
 
-    def max_abs(self) -> torch.Tensor:
-        """max |value| over the computed states, as a 0-d device tensor (one reduction kernel, enqueued on the current stream).
-        The fp16-plane numerics modes keep operand copies of the residual stream in fp16 (range 65 504): the drivers watch this."""
-        return self.states[: self.computed, : self.frame_offs[-1]].abs().amax()
+    # fp16 range guard (round 5): every kernel that rounds a value to an fp16 operand plane (GEMM / row-kernel epilogues in the f16x, f16m,
+    # f16a, f16q, f16 modes) ORs into the slot's device word -- bit 0: a value beyond +-65504 (it saturated), bit 1: beyond half of that.
+    # ``range_flag`` is that word (int32 [1] on the device, None in the bf16-plane modes); the caller reads it back with the features
+    # and clears it (``take_range_bits``).  Round 4 reduced max|hidden state| with a torch pass on sampled batches only.
+    range_flag: Optional[torch.Tensor] = None
+
+    def take_range_bits(self, pinned_out: Optional[torch.Tensor] = None):
+        """Enqueue (current stream) the read-back of the guard word into ``pinned_out`` (int32 [1], page-locked) and its reset; with no
+        buffer given: synchronous, returns the bits.  0 in the modes that keep no fp16 planes."""
+        if self.range_flag is None:
+            if pinned_out is not None:
+                pinned_out.zero_()
+            return 0
+        if pinned_out is not None:
+            pinned_out.copy_(self.range_flag, non_blocking=True)
+            self.range_flag.zero_()
+            return None
+        bits = int(self.range_flag.item())
+        self.range_flag.zero_()
+        return bits
 
 
 class _EncoderBase:
@@ -248,8 +264,22 @@ class _EncoderBase:
         # when a list, every encoder layer appends (start_event, end_event, utterances) around its attention block
         # (packed QKV projection -> attention -> output projection): bench.py's "attention_block" figure
         self.block_trace: Optional[list] = None
+        # operand copies with fp16's range: the guard word is live (SER_NO_RANGE_GUARD=1: A/B knob for tools/, never the drivers)
+        self.fp16_planes = mode in ("f16x", "f16m", "f16a", "f16q", "f16") and _os.environ.get("SER_NO_RANGE_GUARD", "0") != "1"
+        self._flag: Optional[int] = None    # device address of the range-guard word of the slot being launched / recorded
         self._st: Optional[int] = None      # launch stream of the forward in progress (looked up once per forward)
         self._rec: Optional[Tape] = None    # when set, the launch helpers record into it instead of launching
+
+    def _guard_word(self, pl) -> Optional[torch.Tensor]:
+        """the slot's range-guard word (allocated with the plan); launch helpers pick its address up from ``self._flag``"""
+        if not self.fp16_planes:
+            self._flag = None
+            return None
+        t = pl.get("range_flag")
+        if t is None:
+            t = pl["range_flag"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._flag = t.data_ptr()
+        return t
 
     def _check_last_state(self, last_state: Optional[int]) -> Optional[int]:
         if last_state is None:
@@ -361,6 +391,7 @@ class _EncoderBase:
         if ln_mean is not None:                 # consumer side: (shift of the A rows, absolute row mean out)
             g.ln_shift, g.mean_out = _ptr(ln_mean[0]), ln_mean[1].data_ptr()
         g.lnstat_out = _ptr(lnstat_out)         # (relative mean, rstd) of the A rows for the attention kernel's in-kernel gate
+        g.range_flag = self._flag if out_act is not None else None
         if g.mode == _lib.MODE_FP16M:           # block scales of both operands
             g.a_scale, g.a_scale_ld = a.scale.data_ptr(), a.scale_ld
             g.w_scale, g.w_scale_ld = lin.wscale.data_ptr(), lin.wscale.shape[1]
@@ -401,15 +432,15 @@ class _EncoderBase:
         ops = 0 if out_act is None else out_act.plane_stride
         ldo_f32 = D if out_f32 is not None else 0
         rec = self._rec
+        a = rec.slot("layernorm") if rec is not None else _lib.LayerNormArgs()
+        a.x, a.ldx, a.g, a.b, a.eps, a.gelu = x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu)
+        a.out_f32, a.ldo_f32, a.out_act, a.ldo_act, a.out_plane_stride = _ptr(out_f32), ldo_f32, o_act, ldo_act, ops
+        a.mode, a.rows, a.D = mode, rows, D
+        a.range_flag = self._flag if out_act is not None else None
         if rec is not None:
-            a = rec.slot("layernorm")
-            a.x, a.ldx, a.g, a.b, a.eps, a.gelu = x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu)
-            a.out_f32, a.ldo_f32, a.out_act, a.ldo_act, a.out_plane_stride = _ptr(out_f32), ldo_f32, o_act, ldo_act, ops
-            a.mode, a.rows, a.D = mode, rows, D
             rec.commit(_lib.OP_LAYERNORM, a, rows=rows)
             return
-        check(lib.ser_layernorm(x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), eps, int(gelu), _ptr(out_f32), ldo_f32,
-                                o_act, ldo_act, ops, mode, rows, D, self._s()), "ser_layernorm")
+        check(lib.ser_layernorm_v(C.byref(a), self._s()), "ser_layernorm")
 
     def _row_center(self, x: torch.Tensor, out_act: Act, stats: torch.Tensor, shift: torch.Tensor, rows: int, D: int):
         """hidden_states[0] -> centred operand copy + row partials + shift for encoder layer 0 (ser_row_center)."""
@@ -421,6 +452,7 @@ class _EncoderBase:
             a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.x_mode, rows, D
             if out_act.scale is not None:
                 a.out_scale, a.out_scale_ld = out_act.scale.data_ptr(), out_act.scale_ld
+            a.range_flag = self._flag
             rec.commit(_lib.OP_ROW_CENTER, a, rows=rows)
             return
         a = _lib.RowCenterArgs()
@@ -428,6 +460,7 @@ class _EncoderBase:
         a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.x_mode, rows, D
         if out_act.scale is not None:
             a.out_scale, a.out_scale_ld = out_act.scale.data_ptr(), out_act.scale_ld
+        a.range_flag = self._flag
         check(lib.ser_row_center_v(C.byref(a), self._s()), "ser_row_center")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
@@ -569,6 +602,7 @@ class _EncoderBase:
         projection -> attention -> output projection -- over the buffers the slot's last forward left behind (same shapes,
         same kernels, stale but finite data), on the current stream.  Returns the number of layer calls."""
         pl = self._plan(lengths, slot)
+        self._guard_word(pl)
         geo = self.geo
         M, D, B = pl["M"], geo.hidden, len(lengths)
         max_frames = pl.get("Tmax", geo.max_source_positions)
@@ -643,6 +677,8 @@ class _EncoderBase:
         gD = self._stat_groups(D)
         pl["xa"] = self._new_act(M, D, mode=self.x_mode)
         pl["ha"] = self._new_act(M, D)
+        if self.fp16_planes:
+            pl["range_flag"] = torch.zeros(1, dtype=torch.int32, device=dev)   # the slot's fp16 range-guard word (HiddenStates.range_flag)
         # row partial sums (sum, sum^2 per 64-column group).  One buffer per producer layout: a padding
         # slot (odd group count) is never written and must stay zero.
         pl["px0"] = torch.zeros((M, first_groups, 2), dtype=torch.float32, device=dev)   # states[0] (ser_row_center)
@@ -963,6 +999,7 @@ class SpeechEncoder(_EncoderBase):
         the launches that feed later states are skipped)."""
         pl = self._plan(lengths, slot)
         last_state = self._check_last_state(last_state)
+        flag = self._guard_word(pl)
         if not self.use_tape or self.gemm_trace is not None or self.block_trace is not None:
             self._launches(pl, packed_wave, last_state)      # eager: one Python -> C transition per kernel
         else:
@@ -977,7 +1014,9 @@ class SpeechEncoder(_EncoderBase):
                 ar["tape"] = tape
             tape.inputs["wav"].wav = packed_wave.data_ptr()
             tape.run(pl["sizes"], self._s(), last_state)
-        return HiddenStates(pl["states"], pl["frame_offs_host"], None if last_state is None else last_state + 1)
+        hs = HiddenStates(pl["states"], pl["frame_offs_host"], None if last_state is None else last_state + 1)
+        hs.range_flag = flag
+        return hs
 
     def _launches(self, pl, packed_wave: torch.Tensor, last_state: Optional[int] = None) -> None:
         geo = self.geo
@@ -986,17 +1025,16 @@ class SpeechEncoder(_EncoderBase):
         # Conv1d(1,C,10,5)+LayerNorm+GELU on the matrix cores (K padded to 64, LayerNorm epilogue)
         fr = pl["frames"]
         rec = self._rec
+        a = rec.slot("wave_frames") if rec is not None else _lib.WaveFramesArgs()
+        a.wav, a.sample_offs, a.frame_offs = packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr()
+        a.B, a.k, a.stride, a.mode = B, geo.conv_kernel[0], geo.conv_stride[0], self.stem_mode
+        a.out, a.out_plane_stride, a.work, a.total_rows = fr.ptr, fr.plane_stride, pl["wave_work"].data_ptr(), pl["rows"][0]
+        a.range_flag = self._flag
         if rec is not None:
-            a = rec.slot("wave_frames")
-            a.wav, a.sample_offs, a.frame_offs = packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr()
-            a.B, a.k, a.stride, a.mode = B, geo.conv_kernel[0], geo.conv_stride[0], self.stem_mode
-            a.out, a.out_plane_stride, a.work, a.total_rows = fr.ptr, fr.plane_stride, pl["wave_work"].data_ptr(), pl["rows"][0]
             rec.inputs["wav"] = a
             rec.commit(_lib.OP_WAVE_FRAMES, a, B=B, total_rows=pl["rows"][0])
         else:
-            check(lib.ser_wave_frames(packed_wave.data_ptr(), pl["sample_offs"].data_ptr(), pl["frame_offs0"].data_ptr(), B,
-                                      geo.conv_kernel[0], geo.conv_stride[0], fr.ptr, fr.plane_stride, self.stem_mode,
-                                      pl["wave_work"].data_ptr(), pl["rows"][0], self._s()), "ser_wave_frames")
+            check(lib.ser_wave_frames_v(C.byref(a), self._s()), "ser_wave_frames")
         a_in = pl["conv_act"][0]
         self._gemm(fr, self.conv0, pl["rows"][0], act=_lib.ACT_GELU, ln=self.conv_ln[0], ln_eps=1e-5, out_act=a_in,
                    k_algo=geo.conv_kernel[0], stem=True)
@@ -1148,6 +1186,7 @@ class WhisperEncoder(_EncoderBase):
         ``last_state`` = N stops after hidden state N (``--n_layer N``, preprocess_whisper.py:71)."""
         pl = self._plan(lengths, slot)
         last_state = self._check_last_state(last_state)
+        flag = self._guard_word(pl)
         if not self.use_tape or self.gemm_trace is not None or self.block_trace is not None:
             self._logmel(pl, packed_wave)
             self._encoder_launches(pl, pl["mel"], last_state)
@@ -1163,7 +1202,9 @@ class WhisperEncoder(_EncoderBase):
                 pl["tape"] = tape
             tape.inputs["wav"].wav = packed_wave.data_ptr()
             tape.run({}, self._s(), last_state)
-        return HiddenStates(pl["states"], pl["frame_offs_host"], None if last_state is None else last_state + 1)
+        hs = HiddenStates(pl["states"], pl["frame_offs_host"], None if last_state is None else last_state + 1)
+        hs.range_flag = flag
+        return hs
 
     @_on_stream
     def forward_features(self, input_features: torch.Tensor, lengths: Sequence[int], slot: int = 0) -> HiddenStates:
@@ -1173,8 +1214,11 @@ class WhisperEncoder(_EncoderBase):
         if tuple(input_features.shape) != (pl["B"], geo.n_mels, self.N_FRAMES):
             raise ValueError(f"Whisper expects input_features of shape {(pl['B'], geo.n_mels, self.N_FRAMES)}, "
                              f"got {tuple(input_features.shape)}")
+        flag = self._guard_word(pl)
         self._encoder_launches(pl, input_features)
-        return HiddenStates(pl["states"], pl["frame_offs_host"])
+        hs = HiddenStates(pl["states"], pl["frame_offs_host"])
+        hs.range_flag = flag
+        return hs
 
     def _encoder_launches(self, pl, input_features: torch.Tensor, last_state: Optional[int] = None) -> None:
         geo = self.geo
@@ -1182,14 +1226,14 @@ class WhisperEncoder(_EncoderBase):
         T1, T2 = self.N_FRAMES, geo.max_source_positions
         ma = pl["mel_act"]
         rec = self._rec
+        a = rec.slot("pack_act") if rec is not None else _lib.PackActArgs()
+        a.x, a.out, a.ldo, a.out_plane_stride = input_features.data_ptr(), ma.ptr, nm, ma.plane_stride
+        a.B, a.C, a.T, a.halo, a.mode = B, nm, T1, 1, self.stem_mode
+        a.range_flag = self._flag
         if rec is not None:
-            a = rec.slot("pack_act")
-            a.x, a.out, a.ldo, a.out_plane_stride = input_features.data_ptr(), ma.ptr, nm, ma.plane_stride
-            a.B, a.C, a.T, a.halo, a.mode = B, nm, T1, 1, self.stem_mode
             rec.commit(_lib.OP_PACK_ACT, a)
         else:
-            check(lib.ser_pack_act(input_features.data_ptr(), B, nm, T1, 1, ma.ptr, nm, ma.plane_stride, self.stem_mode,
-                                   self._s()), "ser_pack_act")
+            check(lib.ser_pack_act_v(C.byref(a), self._s()), "ser_pack_act")
         # stem: gelu(conv1 k3 p1), gelu(conv2 k3 s2 p1) + embed_positions -> hidden_states[0]
         self._gemm(ma, self.conv1, B * T1, a_rowoff=pl["c1_rowoff"], act=_lib.ACT_GELU, out_act=pl["c1_act"],
                    out_rowmap=pl["c1_rowmap"], stem=True)
@@ -1276,6 +1320,7 @@ class TextEncoder(_EncoderBase):
         geo = self.geo
         B, T = ids.shape
         pl = self._plan(B, T, slot)
+        flag = self._guard_word(pl)
         M, D = pl["M"], geo.hidden
         states = pl["states"]
         xa = pl["xa"]
@@ -1293,7 +1338,9 @@ class TextEncoder(_EncoderBase):
             self._gemm(pl["ha"], lay["fc1"], M, act=_lib.ACT_GELU, out_act=pl["ffn"])
             self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=pl["tmp"], ldo_f32=D)
             self._layernorm(pl["tmp"], D, lay["ln2"], M, D, out_f32=states[i + 1], out_act=xa)
-        return HiddenStates(states, pl["frame_offs_host"])
+        hs = HiddenStates(states, pl["frame_offs_host"])
+        hs.range_flag = flag
+        return hs
 
 
 def _deberta_log_bucket(rel: torch.Tensor, bucket_size: int, max_position: int) -> torch.Tensor:
@@ -1430,6 +1477,7 @@ class DebertaEncoder(_EncoderBase):
         geo = self.geo
         B, T = ids.shape
         pl = self._plan(B, T, slot)
+        flag = self._guard_word(pl)
         M, D, H, dh = pl["M"], geo.hidden, geo.heads, geo.head_dim
         win = pl["win"]
         Nr = win["Nr"]
@@ -1472,7 +1520,9 @@ class DebertaEncoder(_EncoderBase):
                 self._layernorm(pl["tmp"], D, self.text_conv["ln"], M, D, out_f32=states[1], out_act=xa)
                 check(lib.ser_zero_padded_rows(states[1].data_ptr(), D, xa.ptr, D, xa.plane_stride, self.mode, key_lens.data_ptr(),
                                                B, T, D, st), "ser_zero_padded_rows")
-        return HiddenStates(states, pl["frame_offs_host"])
+        hs = HiddenStates(states, pl["frame_offs_host"])
+        hs.range_flag = flag
+        return hs
 
 
 def mean_last4(hs: HiddenStates) -> torch.Tensor:

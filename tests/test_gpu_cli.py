@@ -371,7 +371,8 @@ def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, ca
 def test_fp16_range_guard_fails_the_files_instead_of_clipping(tmp_path, capsys):
     """The default numerics mode keeps operand copies on fp16 planes (range 65 504).  A checkpoint whose residual stream leaves that
     range (here: a feed-forward output bias of 1e5 in one channel, 100x the "massive activation" of the outlier fixtures) must not
-    yield silently clipped features: the driver watches max|hidden state| on the device and reports every file of such a batch as
+    yield silently clipped features: the kernels report every value they round to an fp16 plane into the slot's guard word (round 5; round 4
+    watched max|hidden state| on sampled batches), the driver reads it with every batch and reports every file of such a batch as
     ``Failed to process ...`` with the way out (--mode fp32x: bf16 planes, fp32 range), where the same checkpoint extracts fine."""
     from safetensors.torch import save_file
     from interspeech_ser_amd import config as C
@@ -401,6 +402,65 @@ def test_fp16_range_guard_fails_the_files_instead_of_clipping(tmp_path, capsys):
         assert "Failed to process" not in log and sorted(os.listdir(out2)) == ["u0.pt", "u1.pt", "u2.pt"]
         t = torch.load(out2 / "u0.pt")
         assert float(t.abs().max()) > 9.0e4                                                     # the value the fp16 planes could not hold
+    finally:
+        C._REGISTRY.pop("tiny-range-test")
+
+
+def test_fp16_range_guard_sees_the_feed_forward_intermediate(tmp_path, capsys):
+    """Round 5: the guard is a device word that EVERY kernel rounding to an fp16 operand plane reports into (ser_gemm_args.range_flag and
+    the row kernels'), read back with every batch.  A checkpoint whose FC1 / GELU output leaves the fp16 range while every hidden state
+    stays far below it -- intermediate_dense scaled up by 3e4, output_dense down by the same factor, so the residual stream is the
+    unscaled one -- passed round 4's watch (max |hidden state| on sampled batches) and wrote features computed from saturated operands.
+    Now all files of such a batch fail with the --mode fp32x hint in the fp16-plane modes (f16x default, f16m), and extract in fp32x;
+    the same checkpoint scaled by 1e4 (beyond half the range only) extracts with the one-line warning.
+    Contract: preprocessing/preprocess_speech.py:46,72-73 -- a bad file is a printed failure, never silent garbage."""
+    from safetensors.torch import save_file
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd import driver
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_WAVLM
+    wav_dir = tmp_path / "wav"
+    wav_dir.mkdir()
+    for i, n in enumerate((16000, 9000, 12000)):
+        write_wav(wav_dir / f"u{i}.wav", synth(80 + i, n))
+
+    def checkpoint(factor, name):
+        sd = synthetic_state_dict(geo, 43)
+        for i in range(geo.num_layers):
+            p = f"encoder.layers.{i}.feed_forward"
+            sd[p + ".intermediate_dense.weight"] *= factor
+            sd[p + ".intermediate_dense.bias"] *= factor
+            sd[p + ".output_dense.weight"] /= factor
+        ck = tmp_path / name
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(ck))
+        return ck
+
+    C._REGISTRY["tiny-range-test"] = geo
+    try:
+        ck = checkpoint(3.0e4, "ffn_huge.safetensors")
+        for mode in ("f16x", "f16m"):
+            out = tmp_path / f"pt_{mode}"
+            assert driver.run_speech(["--ssl_type", "tiny-range-test", "--wav_dir", str(wav_dir), "--save_path", str(out), "--checkpoint", str(ck),
+                                      "--use_n_layer", "--n_layer", "-1", "--mode", mode]) == 0
+            log = capsys.readouterr().out
+            assert log.count("Failed to process") == 3 and "fp16 operand range" in log and "--mode fp32x" in log, log
+            assert os.listdir(out) == []
+        out2 = tmp_path / "pt_fp32x"
+        assert driver.run_speech(["--ssl_type", "tiny-range-test", "--wav_dir", str(wav_dir), "--save_path", str(out2), "--checkpoint", str(ck),
+                                  "--use_n_layer", "--n_layer", "-1", "--mode", "fp32x"]) == 0
+        log = capsys.readouterr().out
+        assert "Failed to process" not in log and sorted(os.listdir(out2)) == ["u0.pt", "u1.pt", "u2.pt"]
+        t = torch.load(out2 / "u0.pt")
+        assert float(t.abs().max()) < 100.0                      # ... while every hidden state is small: round 4's watch saw nothing
+        # GELU of the scaled pre-activations: ~1e4 x the plain ones (a few units) -> beyond half the range, inside it: warning, files written
+        ck2 = checkpoint(4.0e3, "ffn_large.safetensors")
+        out3 = tmp_path / "pt_warn"
+        assert driver.run_speech(["--ssl_type", "tiny-range-test", "--wav_dir", str(wav_dir), "--save_path", str(out3), "--checkpoint", str(ck2),
+                                  "--use_n_layer", "--n_layer", "-1"]) == 0
+        log = capsys.readouterr().out
+        assert "Failed to process" not in log and sorted(os.listdir(out3)) == ["u0.pt", "u1.pt", "u2.pt"], log
+        if "within a factor 2 of the fp16 operand range" in log:
+            assert log.count("WARNING: values within a factor 2") == 1
     finally:
         C._REGISTRY.pop("tiny-range-test")
 
