@@ -29,6 +29,9 @@
 #ifndef SER_GEMM_PP
 #define SER_GEMM_PP 27        // ping-pong schedule, bit mask: 1 = 256x256, 2 = 256x128 / 64x512 (64x64 wave tiles), 4 = 128x512 LayerNorm tile, 8 = the FP32X 128x128 tile, 16 = the FP32X 128x512 LayerNorm tile; 0 = plain ring (A/B builds)
 #endif
+#ifndef SER_GEMM_PSW
+#define SER_GEMM_PSW 0        // the hand-placed software pipeline instead of the ping-pong phases on the 8-wave single-plane tiles: 1 = 256x256, 2 = 256x128 (two-stage ring)
+#endif
 #ifndef SER_M16_READS_FIRST
 #define SER_M16_READS_FIRST 1  // FP16M ping-pong loop: fragment reads of a unit are issued before its DMAs (0: DMAs first, like the other tiles)
 #endif
@@ -115,7 +118,7 @@ __device__ __forceinline__ void mfma_scale_drain() {
 // (Round 3's persistent form -- only the resident blocks are launched and each walks several tiles -- measured -8 % on the step and was
 // removed from the kernel in round 4; DESIGN.md section 10 keeps the record.)
 template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
-__global__ __launch_bounds__(64 * WM * WN, 2)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN == 64) ? 1 : 2)
 void ser_gemm_kernel(const ser_gemm_args p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -236,7 +239,11 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         sc_off = (uint32_t)i * 4u;
     }
     int i_kk = 0, i_cc = 0, i_cj = 0, i_stage = 0;                               // issue-side scalar state
-    auto issue = [&]() {
+    // one ring unit = LPT DMA pieces per wave.  issue() sends them back to back; the software-pipelined 4-wave tile sends them one at a time
+    // between its MFMAs (issue_begin / issue_piece(j) / issue_end).
+    const char* is_ua = nullptr; const char* is_uw = nullptr;
+    uint32_t is_dstA = 0, is_dstW = 0;
+    auto issue_begin = [&]() {
         int64_t koffA = (int64_t)i_cj * p.ldj + (int64_t)i_cc * BK;
         int64_t koffW = (int64_t)i_kk * BK;
         if constexpr (M16) {                                     // unit i_kk: K tile i_kk / 2, plane i_kk & 1 (same byte offsets in both planes)
@@ -244,20 +251,26 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             koffW = (int64_t)(i_kk >> 1) * BK + (i_kk & 1) * p.w_plane_stride;
             if (i_kk & 1) dma_lds<4>(sc_base + (int64_t)(i_kk >> 1) * sc_step, sc_off, lds0 + (uint32_t)(ST * STAGE + (LNEPI ? 0 : BM * 8) + (i_stage * SCW + sc_chunk * 64) * 4));
         }
-        const uint32_t dstA = lds0 + i_stage * STAGE + wave * 1024;   // stage = [A hi][A lo][W hi][W lo]
-        const uint32_t dstW = dstA + NPL * A_BYTES;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            const char* ua = Atile + (koffA + pl * p.a_plane_stride) * 2;
-            const char* uw = Wtile + (koffW + pl * p.w_plane_stride) * 2;
-#pragma unroll
-            for (int q = 0; q < LA; ++q) dma_lds<16>(ua, aoff[q], dstA + pl * A_BYTES + q * NW * 1024);
-#pragma unroll
-            for (int q = 0; q < LW; ++q) dma_lds<16>(uw, woff[q], dstW + pl * W_BYTES + q * NW * 1024);
-        }
+        is_dstA = lds0 + i_stage * STAGE + wave * 1024;          // stage = [A hi][A lo][W hi][W lo]
+        is_dstW = is_dstA + NPL * A_BYTES;
+        is_ua = Atile + koffA * 2;
+        is_uw = Wtile + koffW * 2;
+    };
+    auto issue_piece = [&](int j) {                              // j in [0, LPT): plane-major, A pieces then W pieces (compile-time j)
+        const int pl = j / (LA + LW), q = j % (LA + LW);
+        if (q < LA) dma_lds<16>(is_ua + (int64_t)pl * p.a_plane_stride * 2, aoff[q < LA ? q : 0], is_dstA + pl * A_BYTES + q * NW * 1024);
+        else dma_lds<16>(is_uw + (int64_t)pl * p.w_plane_stride * 2, woff[q >= LA ? q - LA : 0], is_dstW + pl * W_BYTES + (q - LA) * NW * 1024);
+    };
+    auto issue_end = [&]() {
         ++i_kk; ++i_cc;
         if (i_cc == tpc) { i_cc = 0; ++i_cj; }
         i_stage = (i_stage + 1 == ST) ? 0 : i_stage + 1;
+    };
+    auto issue = [&]() {
+        issue_begin();
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) issue_piece(j);
+        issue_end();
     };
 
     f32x4 acc[TN][TM];
@@ -308,7 +321,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                 }
         }
     };
-    if constexpr (!M16) load_cols();
+    constexpr bool LATE_COLS = M16 || (WM * WN == 4 && TM * TN == 64) || (SER_GEMM_PSW != 0 && WM * WN == 8 && BK == 64 && ST == 2 && !LNEPI && mode_traits<MODE>::planes == 1);      // ... and the 4-wave 256x256 tile: its 256 non-accumulator registers
+    if constexpr (!LATE_COLS) load_cols();                                  // hold two fragment buffers (128) already
 
 #pragma unroll
     for (int t = 0; t < ST - 1; ++t)
@@ -360,7 +374,8 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int PP_BIT = NPL == 2 ? (LNEPI ? 16 : 8) : (LNEPI ? 4 : (TM * TN >= 32 ? 1 : 2));
-    constexpr bool PP = !M16 && (SER_GEMM_PP & PP_BIT) && NW == 8 && (KS == 2 || NPL == 2);
+    constexpr bool PSW8 = NPL == 1 && !M16 && KS == 2 && ST == 2 && !LNEPI && NW == 8 && ((TM * TN == 32 && (SER_GEMM_PSW & 1)) || (TM * TN == 16 && (SER_GEMM_PSW & 2)));
+    constexpr bool PP = !M16 && !PSW8 && (SER_GEMM_PP & PP_BIT) && NW == 8 && (KS == 2 || NPL == 2);
     constexpr int PH = (NPL == 1 && TM * TN >= 32) ? KS : 1;          // read phases per K tile (FP32X: 12 fragments + 24 MFMAs per k-step, one phase)
     constexpr int SPP = KS / PH;                                      // k-steps per phase
     // FP32X tiles with 64x128 wave tiles (the LayerNorm tile: one k-step per 32-deep K tile, 24 fragments, 96 MFMAs): the two read
@@ -665,9 +680,85 @@ void ser_gemm_kernel(const ser_gemm_args p) {
             }
         }
     }
+    // ---- 256x256 on FOUR waves, one per SIMD, hand-placed software pipeline (round 5; the round-4 verdict's "one bounded attempt").
+    // A wave owns 128x128 of the tile (64 MFMA tiles, 256 accumulator registers of its 512) and nothing else runs on its SIMD, so every
+    // latency has to pass under its own MFMAs: the 64 MFMAs of a k-step are issued in groups of four with ONE other instruction behind each
+    // group -- the 16 fragment reads of the NEXT k-step (second fragment buffer) and, in the second k-step of a K tile, the 16 DMA pieces of
+    // the tile two ahead -- and a sched_barrier after every group keeps hipcc from regrouping them (left alone it clusters the reads in
+    // front: the compiler-scheduled form of this tile lost 30 % in round 2).  One s_barrier per K tile, at the start of its second k-step:
+    // behind it every wave's pieces of tile kt + 1 have landed (they were issued a whole K tile earlier) and every wave has read the last
+    // fragments of tile kt - 1's stage... which the DMAs that follow refill.
+    // The same pipeline on the 8-wave tiles (SER_GEMM_PSW bit 1: 256x256, bit 2: 256x128 on a TWO-stage ring): two waves per SIMD each run it on
+    // their own 128x64 / 64x64 wave tile and share the matrix pipe instruction by instruction instead of phase by phase.
+    constexpr bool P4 = NPL == 1 && !M16 && KS == 2 && ST == 2 && !LNEPI &&
+                        ((NW == 4 && TM * TN == 64) || (NW == 8 && TM * TN == 32 && (SER_GEMM_PSW & 1)) || (NW == 8 && TM * TN == 16 && (SER_GEMM_PSW & 2)));
+    if constexpr (P4) {
+        constexpr int NM = TM * TN, NF = TM + TN;                     // MFMAs and fragment reads per k-step
+        constexpr int RS = (NM * 3 / 4) / NF < 1 ? 1 : (NM * 3 / 4) / NF;   // a fragment read behind every RS-th MFMA: the last quarter of the MFMAs covers the last read's latency
+        static_assert(LPT <= NF, "DMA pieces per wave fit the read slots");
+        bf16x8 fa[2][TM], fw[2][TN];
+        auto frag_read = [&](const char* sb, int step, int j, int buf) {         // j in [0, NF): A fragments first (the first MFMAs need all of them)
+            if (j < TM) fa[buf][j < TM ? j : 0] = *(const bf16x8*)(sb + offA[step] + j * 16 * ROWB);
+            else fw[buf][j >= TM ? j - TM : 0] = *(const bf16x8*)(sb + offW[step] + (j - TM) * 16 * ROWB);
+        };
+        if (1 < total) issue();                                       // tiles 0 and 1 in flight
+        if (1 < total) wait_vmcnt<LPT>(); else wait_vmcnt<0>();       // tile 0 has landed
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < NF; ++j) frag_read(lds, 0, j, 0);
+        // the side instructions sit behind MFMAs 2, 5, 8, ... 47 (reads) and 0, 3, ... 45 (DMA pieces): the last 16 MFMAs of a k-step cover
+        // the latency of its last fragment read.  The MFMAs are issued from inline asm with the accumulator TIED and in the accumulation half
+        // of the register file ("+a"): with the builtin hipcc moved the 256 accumulators between VGPRs, AGPRs and scratch across the loop's
+        // branches (341 spilled registers, 144 v_accvgpr moves per k-step).  Consecutive MFMAs target different accumulators; the fragment
+        // registers come from ds_read (the compiler waits lgkmcnt for asm operands like for any other use); mfma_drain() before the epilogue.
+        auto mma = [&](f32x4& c, const bf16x8& w, const bf16x8& x) {
+            if constexpr (mode_traits<MODE>::f16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
+        };
+        auto step0 = [&](const char* sb) {                            // MFMAs on buffer 0; the fragments of k-step 1 go to buffer 1
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                mma(acc[i / TM][i % TM], fw[0][i / TM], fa[0][i % TM]);
+                if (i % RS == RS - 1 && i / RS < NF) { frag_read(sb, 1, i / RS, 1); __builtin_amdgcn_sched_barrier(0); }
+            }
+        };
+        auto step1 = [&](const char* sbn, auto more_tag, auto next_tag) {
+            constexpr bool MORE = decltype(more_tag)::value, NEXT = decltype(next_tag)::value;
+            // behind the barrier tile kt + 1 is visible to every wave and tile kt's stage has been read out by every wave (its last fragment
+            // reads were issued 16 MFMAs ago): the DMAs of tile kt + 2 may refill it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (NEXT) {
+                wait_vmcnt<0>();                                      // the pieces of tile kt + 1 (issued a K tile ago): nothing younger is in flight
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MORE) issue_begin();
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                mma(acc[i / TM][i % TM], fw[1][i / TM], fa[1][i % TM]);
+                if constexpr (MORE) { if (i % RS == 0 && i / RS < LPT) { issue_piece(i / RS); __builtin_amdgcn_sched_barrier(0); } }
+                if constexpr (NEXT) { if (i % RS == RS - 1 && i / RS < NF) { frag_read(sbn, 0, i / RS, 0); __builtin_amdgcn_sched_barrier(0); } }
+            }
+            if constexpr (MORE) issue_end();
+        };
+        int kt = 0;
+        for (; kt + 2 < total; ++kt) {                                // steady state: no branch inside a K tile
+            step0(lds + (kt & 1) * STAGE);
+            step1(lds + ((kt + 1) & 1) * STAGE, std::true_type{}, std::true_type{});
+        }
+        if (kt + 1 < total) {                                         // second to last tile: nothing left to fetch
+            step0(lds + (kt & 1) * STAGE);
+            step1(lds + ((kt + 1) & 1) * STAGE, std::false_type{}, std::true_type{});
+            ++kt;
+        }
+        step0(lds + (kt & 1) * STAGE);                                // last tile
+        step1(lds, std::false_type{}, std::false_type{});
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the last MFMAs have written their accumulators
+    }
     if constexpr (M16) mfma_scale_drain();
     int c_stage = 0;
-    for (int kt = 0; kt < ((PP || M16) ? 0 : total); ++kt) {
+    for (int kt = 0; kt < ((PP || M16 || P4) ? 0 : total); ++kt) {
         // tile kt has landed once at most (ST-2) younger tiles are still in flight
         if (kt + (ST - 2) < total) wait_vmcnt<LPT * (ST - 2)>();
         else wait_vmcnt<0>();
@@ -746,7 +837,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         }
     }
 #endif
-    if constexpr (M16) load_cols();
+    if constexpr (LATE_COLS) load_cols();
     // ---- epilogue: lane owns row m (per mi) and TN*4 consecutive columns ----------------------
     float ramax = 0.f;                            // largest |value| this lane rounded to an fp16 operand plane (range guard)
     if constexpr (LNEPI) {
@@ -1010,7 +1101,7 @@ void ser_gemm_kernel(const ser_gemm_args p) {
 #endif
 
 // ------------------------------------------------------------------------------------------------
-enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN512_M64 = 4, CFG_LN512_M32 = 5, CFG_128x64 = 6 };
+enum { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_LN512 = 3, CFG_LN512_M64 = 4, CFG_LN512_M32 = 5, CFG_128x64 = 6, CFG_256x256_W4 = 7 };
 
 template <int WM, int WN, int TM, int TN, int BK, int ST, int MODE, bool LNEPI, int OM = MODE>
 static hipError_t launch_mode(const ser_gemm_args* a, dim3 grid, dim3 block, int LDS, hipStream_t s) {
@@ -1093,6 +1184,9 @@ static int pick_cfg(const ser_gemm_args* a) {
         const int bm = force_bm ? force_bm : (a->M >= 200 * 128 ? 128 : (a->M >= 200 * 64 ? 64 : 32));
         return bm == 128 ? CFG_LN512 : (bm == 64 ? CFG_LN512_M64 : CFG_LN512_M32);
     }
+#ifdef SER_EXPERIMENTS
+    if (a->tile_cfg == 4) return CFG_256x256_W4;
+#endif
     if (a->tile_cfg > 0) return a->tile_cfg - 1;
     // Measured on MI355X (tools/gemm_sweep.py, M = 7984): the simple ring keeps the 128x128 tile
     // (2 blocks/CU) ahead of 256x128 on every N <= 3072 shape; 256x256 wins once it has >= ~2 full
@@ -1181,7 +1275,11 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
     if (a->col_scale_end % 4) return ser_fail(-17, "ser_gemm: col_scale_end must be a multiple of 4");
     if ((a->ldo_act % 8) || (a->c_group_stride % 8)) return ser_fail(-18, "ser_gemm: act pitch / group stride must be multiples of 8");
     if (a->f32_col_begin < 0 || (a->f32_col_begin % 8)) return ser_fail(-16, "ser_gemm: f32_col_begin must be a non-negative multiple of 8");
+#ifdef SER_EXPERIMENTS
+    if (a->tile_cfg < 0 || a->tile_cfg > 4) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..4)", a->tile_cfg);
+#else
     if (a->tile_cfg < 0 || a->tile_cfg > 3) return ser_fail(-13, "ser_gemm: tile_cfg=%d (0 auto, 1..3)", a->tile_cfg);
+#endif
     hipStream_t s = (hipStream_t)stream;
 #ifdef SER_GEMM_DBG
     {
@@ -1238,7 +1336,14 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         case CFG_LN512_M32: return launch_cfg<1, 4, 2, 8, 64, 2, true>(a, s);   // 32 x 512 tile, 4 waves of 32x128
         case CFG_128x64:  return launch_cfg<4, 1, 2, 4, 64, 2, false>(a, s);    // 4 waves of 32x64: a wave owns a whole 64-column stat group
         case CFG_256x256: return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
-        case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
+#ifdef SER_EXPERIMENTS
+        // four waves of 128x128, one per SIMD, hand-placed software pipeline (round 5): its K loop runs at 89 % of the matrix pipe (FC2 shape: 1.16 us per
+        // 64-deep K tile against ~1.8) but the epilogue of a lone wave per SIMD costs more than the loop saves (QKV 75 against 70 us, FC1 84 / 80);
+        // the same pipeline on the 8-wave tiles (-DSER_GEMM_PSW) is 8 % / 3.5 % faster on QKV / FC1 alone and moves the step by nothing: the step
+        // runs AT THE BOARD'S 1 400 W POWER CAP (profiles/r05_power_sample_bf16_step.txt), cycle savings come back as clock.  make EXPERIMENTS=1 only.
+        case CFG_256x256_W4: return launch_cfg<2, 2, 8, 8, 64, 2, false>(a, s);
+#endif
+        case CFG_256x128: return launch_cfg<4, 2, 4, 4, 64, (SER_GEMM_PSW & 2) ? 2 : 3, false>(a, s);
         default:          return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
     }
 }

@@ -121,11 +121,16 @@ def test_gemm_integer_exact(L, mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 256), (257, 264, 64), (1030, 128, 640), (300, 136, 128), (140, 256, 192), (129, 8, 320)])
 def test_gemm_every_tile_config_integer_exact(L, mode, cfg, M, N, K):
     """128x128 / 256x128 / 256x256 block tiles (2- and 3-stage rings; K = 64..640 covers every ring fill / drain
-    length) forced through tile_cfg."""
+    length) forced through tile_cfg; 4 = the 256x256 tile on four waves with the hand-placed software pipeline (round 5; single-plane
+    modes -- the two-plane mode ignores it; built with `make EXPERIMENTS=1` only: a measured dead end)."""
+    if cfg == 4:
+        import subprocess
+        if b"ser_attention_resident" not in subprocess.run(["nm", "-D", L.LIB_PATH], capture_output=True).stdout:
+            pytest.skip("tile_cfg 4 exists in the EXPERIMENTS build only")
     g = torch.Generator().manual_seed(M + N + cfg)
     A = torch.randint(-3, 4, (M, K), generator=g).float()
     W = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()

@@ -50,6 +50,8 @@ def main():
             g.M, g.N, g.K, g.groups, g.mode, g.act = M, N, K, 1, mode, act
             if mode == 6:
                 g.tile_cfg = int(os.environ.get("SER_BENCH_CFG", "0"))        # 0 auto, 2 = 256x128, 3 = 256x256
+            if mode in (1, 3):
+                g.tile_cfg = int(os.environ.get("SER_BENCH_CFG1", "0"))       # single-plane modes: 4 = 256x256 on four waves
             g.out_act, g.ldo_act, g.out_plane_stride = oa.data_ptr(), N, M * N
             if mode == 6:
                 g.a_scale, g.a_scale_ld, g.w_scale, g.w_scale_ld = As.data_ptr(), M, Ws.data_ptr(), N
