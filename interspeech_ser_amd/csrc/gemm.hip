@@ -1319,13 +1319,15 @@ extern "C" int ser_gemm(const ser_gemm_args* a, void* stream) {
         return launch_cfg<4, 2, 2, 4, 64, 2, false, true>(a, s);      // 128x128 tile on 8 waves (32x64 each): 2 waves/SIMD hide the LDS reads
     }
     if (a->mode == SER_MODE_FP16M) {
-        // the single-plane tiles walked twice per K tile (H unit, E unit): 256x128 on a three-stage ring from 100 tiles up, 128x128 on four waves
-        // below that.  The 256x256 form (two stages of 64 KiB: one unit in flight) is built and exact but not faster at M = 7 984 -- packed projection
-        // 139 us against 122 us on 256x128, FC1 162 against 169 - 175, FC2 206 against 130 (profiles/r05_gemm_f16m_bench.txt) -- so only
-        // tile_cfg = 3 selects it
+        // the single-plane tiles walked twice per K tile (H unit, E unit): 256x256 from 100 tiles up, 256x128 on a three-stage ring, 128x128 on four
+        // waves for small M.  Alone, one launch at a time, the 256x256 form is the SLOWER one at M = 7 984 (packed projection 139 us against 122 on
+        // 256x128, FC2 -- 128 tiles, half the chip -- 206 against 130: profiles/r05_gemm_f16m_bench.txt); on the step it is the FASTER one: 928 ->
+        // 973 utt/s with the packed projection and FC1 on it, 990 with FC2 and the output projection too (profiles/r05_f16m_tile_choice_step_ab.txt).
+        // The step runs at the board's power cap (profiles/r05_power_sample_bf16_step.txt): what counts is energy per FLOP, and the square tile
+        // moves 2/3 of the L2 -> LDS bytes per FLOP.  (The same threshold on the bf16 tiles LOSES 1.3 %: T256_MIN stays 150.)
         const long t256sq = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
         const long t256x128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128);
-        static const long m_sq_min = SER_KNOB("SER_GEMM_M16_SQ_MIN", 1L << 30), m_256_min = SER_KNOB("SER_GEMM_M16_256_MIN", 100);
+        static const long m_sq_min = SER_KNOB("SER_GEMM_M16_SQ_MIN", 100), m_256_min = SER_KNOB("SER_GEMM_M16_256_MIN", 100);
         if (a->tile_cfg == 3 || (!a->tile_cfg && a->N >= 256 && t256sq >= m_sq_min)) return launch_cfg<2, 4, 8, 4, 64, 2, false>(a, s);
         if (a->tile_cfg == 2 || (!a->tile_cfg && a->N >= 128 && t256x128 >= m_256_min)) return launch_cfg<4, 2, 4, 4, 64, 3, false>(a, s);
         return launch_cfg<2, 2, 4, 4, 64, 2, false>(a, s);
