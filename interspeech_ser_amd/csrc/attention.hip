@@ -704,6 +704,13 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
         bias_stride += (16 - (bias_stride & 63) + 64) & 63;
     }
     size_t lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
+    // ... and only while four blocks' LDS fit a CU: a long utterance's bias window (B = 1, ~8 000 frames: 1 008 blocks, 133 KiB of window) would
+    // otherwise take the single-buffer 128-register form at ONE block per CU, the slow combination
+    if (occ && lds > 40 * 1024) {
+        occ = false;
+        nbuf = (nch * (np + npv) <= 8) ? 2 : 1;
+        lds = (size_t)nbuf * (np + npv) * ABKV * dhp * 2 + (size_t)4 * bias_stride * 4;
+    }
     // a bias window that does not fit (utterances beyond ~2 min; ~1.5 min in the two-plane modes): the table is read from global
     // memory instead (GB forms: pre-scaled q, head dim <= 64 -- what the WavLM encoders use)
     const bool gbias = table && lds > 160 * 1024 && scale <= 0.f && dhp == 64 && nwv == 4;

@@ -212,8 +212,12 @@ static int pt_write_f32(const char* path, const float* host_data, int64_t rows, 
     std::string stem(path);
     const size_t slash = stem.find_last_of('/');
     if (slash != std::string::npos) stem = stem.substr(slash + 1);
-    // the host writes "<name>.pt.tmp" and renames it when complete (frontend.save_feature): the archive is <name>.pt's
-    if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".tmp") == 0) stem.resize(stem.size() - 4);
+    // the host writes "<name>.pt.<pid>.tmp" (round 4: "<name>.pt.tmp") and renames it when complete (frontend.save_feature): the archive is <name>.pt's
+    if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".tmp") == 0) {
+        stem.resize(stem.size() - 4);
+        const size_t d = stem.find_last_of('.');
+        if (d != std::string::npos && d + 1 < stem.size() && stem.find_first_not_of("0123456789", d + 1) == std::string::npos) stem.resize(d);
+    }
     const size_t dot = stem.find_last_of('.');
     if (dot != std::string::npos && dot > 0) stem = stem.substr(0, dot);
     if (stem.empty()) stem = "archive";

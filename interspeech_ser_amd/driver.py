@@ -313,13 +313,15 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, l
     # <name>.tmp and renamed when complete; what a killed run left behind is neither a feature file nor part of the count.
     n_existing = 0
     if rank == 0:
+        from .frontend import is_partial, stale_partial
         for fn in os.listdir(args.save_path):
-            if fn.endswith((".pt.tmp", ".npy.tmp")):
-                try:
-                    os.remove(os.path.join(args.save_path, fn))
-                    print(f"Removed stale partial output {fn}")
-                except OSError:
-                    pass
+            if is_partial(fn):                      # never a feature file, never counted; removed only when its writer is gone
+                if stale_partial(args.save_path, fn):
+                    try:
+                        os.remove(os.path.join(args.save_path, fn))
+                        print(f"Removed stale partial output {fn}")
+                    except OSError:
+                        pass
             else:
                 n_existing += 1
     n_existing = D.broadcast_int(n_existing)
@@ -411,9 +413,11 @@ def _run(argv: Optional[Sequence[str]], whisper: bool, extractor_factory=None, l
             out = feature_path(args.save_path, path)
             if args.save_format == "npy":
                 final = out[:-3] + ".npy"
-                with open(final + ".tmp", "wb") as f:        # complete or absent: --skip_existing trusts what it finds
+                from .frontend import tmp_name
+                tmp = tmp_name(final)
+                with open(tmp, "wb") as f:                   # complete or absent: --skip_existing trusts what it finds
                     np.save(f, feats.numpy())
-                os.replace(final + ".tmp", final)
+                os.replace(tmp, final)
             else:
                 save_feature(feats, out)
         except Exception as e:                            # noqa: BLE001

@@ -140,6 +140,41 @@ def feature_path(save_path: str, wav_path: str) -> str:
     return os.path.join(save_path, os.path.splitext(os.path.basename(wav_path))[0] + ".pt")
 
 
+def tmp_name(path: str) -> str:
+    """Name a feature file is written under before it is renamed into place: ``<path>.<pid>.tmp``.  The pid keeps two independent jobs that
+    share a --save_path (sharding by --wav_dir with --use_n_layer is a common way to run the reference script on several GPUs,
+    README.md:41-43) from deleting each other's files in progress (round 4 used ``<path>.tmp`` and removed every such file at start-up)."""
+    return f"{path}.{os.getpid()}.tmp"
+
+
+def is_partial(name: str) -> bool:
+    return name.endswith(".tmp")
+
+
+def stale_partial(save_path: str, name: str, max_age_s: float = 6 * 3600.0) -> bool:
+    """A partial output nobody is writing any more: its writer's pid is gone (same host) or the file has not been touched for hours
+    (another host, or a recycled pid).  ``<path>.tmp`` names of earlier versions count as stale at once."""
+    import time
+    parts = name.split(".")
+    pid = parts[-2] if len(parts) >= 3 and parts[-2].isdigit() else None
+    if pid is None:
+        return True
+    try:
+        if time.time() - os.path.getmtime(os.path.join(save_path, name)) > max_age_s:
+            return True
+    except OSError:
+        return False
+    if int(pid) == os.getpid():
+        return False
+    try:
+        os.kill(int(pid), 0)
+    except ProcessLookupError:
+        return True
+    except OSError:
+        return False
+    return False
+
+
 def save_feature(feats: torch.Tensor, path: str) -> None:
     """``torch.save`` of a bare [T, D] float32 CPU tensor: what the downstream heads
     ``torch.load`` (bin/train_cat_bimodal_lazy_1head.py:220-228)."""
@@ -149,7 +184,7 @@ def save_feature(feats: torch.Tensor, path: str) -> None:
     t = t.to(torch.float32).contiguous()
     # written under a temporary name and renamed when complete: a killed process or a full disk leaves no truncated <name>.pt
     # for --skip_existing (which only asks whether the file exists) to mistake for a finished one
-    tmp = path + ".tmp"
+    tmp = tmp_name(path)
     try:
         if t.dim() == 2 and t.shape[1] > 0:
             # same archive torch.save writes, produced by libserhip's ser_pt_write_f32 without the GIL: the writer threads

@@ -473,12 +473,26 @@ def test_layer_rule_and_resume_do_not_mix_layers_silently(tmp_path, capsys):
         write_wav(wav_dir / f"u{i}.wav", 0.1 * rng.standard_normal(4000))
     out = tmp_path / "pt"
     out.mkdir()
-    (out / "u0.pt.tmp").write_bytes(b"half a file")
+    (out / "u0.pt.tmp").write_bytes(b"half a file")                          # earlier versions' name: stale at once
     (out / "u1.npy.tmp").write_bytes(b"half a file")
+    dead = 1
+    while True:                                                             # a pid nobody has: its partial output is stale
+        dead += 7919
+        try:
+            os.kill(dead, 0)
+        except ProcessLookupError:
+            break
+        except OSError:
+            continue
+    (out / f"u2.pt.{dead}.tmp").write_bytes(b"half a file")
+    # ... and one whose writer is ALIVE (round 5, ADVICE r4: a second job sharing --save_path must not lose its files in progress)
+    live = out / f"other_job.pt.{os.getppid()}.tmp"
+    live.write_bytes(b"being written by somebody else")
     assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out)], whisper=False, extractor_factory=Stub) == 0
     log = capsys.readouterr().out
     assert "It has 0 files in it" in log and "Layer rule: hidden_states[0]" in log and "WARNING" not in log
-    assert log.count("Removed stale partial output") == 2
+    assert log.count("Removed stale partial output") == 3 and live.exists()
+    live.unlink()
     assert sorted(os.listdir(out)) == ["u0.pt", "u1.pt", "u2.pt"] and float(torch.load(out / "u1.pt")[0, 0]) == 0.0
     os.remove(out / "u2.pt")                                                # "a killed run": two of three outputs exist
     assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--skip_existing"], whisper=False, extractor_factory=Stub) == 0
