@@ -89,10 +89,12 @@ def collective_record(world, seconds, nbytes):
             "what": "one flat fp32 broadcast of the frozen weights from rank 0 (dist.broadcast_state_dict); no data-path collective"}
 
 
-def other_encoder_run(name, device, mode, steps=3, warmup=1):
+def other_encoder_run(name, device, mode, steps=3, warmup=1, parity_modes=("f16x", "f16m")):
     """A short, checked run of one of the other encoders BASELINE.json's configs name, so that the driver's record carries a timed line
-    for them too (round-3 verdict, weak #13): seeded synthetic weights (fast generator: throughput only), the launch shape the
-    drivers use for that family, `steps` counted steps of >= 0.3 s; the replayed graph's states must equal the eager path bit for bit."""
+    for them too (round-3 verdict, weak #13): seeded synthetic weights (fast generator), the launch shape the drivers use for that
+    family, `steps` counted steps of >= 0.3 s; the replayed graph's states must equal the eager path bit for bit.  Round 5 (verdict r4
+    #5): the same for the tolerance-grade modes -- the drivers' default f16x and the faster f16m -- each with its worst-state error
+    against the CPU oracle on utterance 0 (full geometry), under ``modes``."""
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import build_encoder
     from interspeech_ser_amd.weights import synthetic_state_dict
@@ -101,44 +103,62 @@ def other_encoder_run(name, device, mode, steps=3, warmup=1):
     geo = C.geometry_for(ssl_type)
     whisper = geo.family == C.FAMILY_WHISPER
     sd = synthetic_state_dict(geo, 0, fast=True)
-    enc = build_encoder(geo, sd, device, mode)
-    del sd
     num_samples = int(round(seconds * 16000))
     inflight, micro = (1, 2) if whisper else (2, 1)
     cuts = [round(i * batch / micro) for i in range(micro + 1)]
     waves = [synth_batch(batch, num_samples, 4242 + j) for j in range(inflight)]
     lengths = [num_samples] * batch
-    groups = [(enc.upload(waves[j][a:b], slot=slot), lengths[a:b])
-              for slot, (j, a, b) in enumerate((j, a, b) for j in range(inflight) for a, b in zip(cuts[:-1], cuts[1:]))]
-    torch.cuda.synchronize()
-    graph, hs = enc.capture_concurrent(groups)
-    for _ in range(warmup):
-        graph.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    graph.replay()
-    torch.cuda.synchronize()
-    reps = max(1, int(0.3 / max(time.perf_counter() - t0, 1e-4) / steps) + 1)
-    t0 = time.perf_counter()
-    for _ in range(steps * reps):
-        graph.replay()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kept = [h.states.clone() for h in hs]
-    eager = [enc.forward(w, l, slot=slot) for slot, (w, l) in enumerate(groups)]
-    torch.cuda.synchronize()
-    same = all(torch.equal(k, e.states) for k, e in zip(kept, eager))
-    finite = all(bool(torch.isfinite(k).all()) for k in kept)
-    utts = batch * inflight * steps * reps
     gf = whisper_gflop_per_utt(geo) if whisper else algorithmic_gflop_per_utt(geo, num_samples)
+    ref = None
+
+    def one_mode(m, with_error):
+        nonlocal ref
+        enc = build_encoder(geo, sd, device, m)
+        groups = [(enc.upload(waves[j][a:b], slot=slot), lengths[a:b])
+                  for slot, (j, a, b) in enumerate((j, a, b) for j in range(inflight) for a, b in zip(cuts[:-1], cuts[1:]))]
+        torch.cuda.synchronize()
+        graph, hs = enc.capture_concurrent(groups)
+        for _ in range(warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        graph.replay()
+        torch.cuda.synchronize()
+        reps = max(1, int(0.3 / max(time.perf_counter() - t0, 1e-4) / steps) + 1)
+        t0 = time.perf_counter()
+        for _ in range(steps * reps):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kept = [h.states.clone() for h in hs]
+        eager = [enc.forward(w, l, slot=slot) for slot, (w, l) in enumerate(groups)]
+        torch.cuda.synchronize()
+        same = all(torch.equal(k, e.states) for k, e in zip(kept, eager))
+        finite = all(bool(torch.isfinite(k).all()) for k in kept)
+        utts = batch * inflight * steps * reps
+        r = {"mode": m, "value": round(utts / dt, 1), "unit": "utterances/s", "steps": steps, "batches_per_step": reps * inflight,
+             "ms_per_batch": round(1e3 * dt / steps / reps / inflight, 3),
+             "achieved_tflops_whole_path": round(utts / dt * gf / 1e3, 1), "frac_of_bf16_peak": round(utts / dt * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
+             "verified": bool(same and finite), "graph_replay_equals_eager_bitwise": bool(same), "all_finite": finite}
+        if with_error:
+            if ref is None:
+                ref = oracle_states(geo, sd, waves[0][0], whisper)        # CPU oracle, utterance 0, all states (checker only)
+            rows = ref[0].shape[0]
+            err = max(rel_err(eager[0].utterance(0, l).cpu()[:rows], x) for l, x in enumerate(ref))
+            r.update({"max_rel_err_vs_oracle": float(f"{err:.3e}"), "tolerance": 1e-3, "within_tolerance": bool(err <= 1e-3)})
+            r["verified"] = bool(r["verified"] and err <= 1e-3)
+        del enc, hs, kept, eager, graph, groups
+        torch.cuda.empty_cache()
+        return r
+
+    timed = one_mode(mode, with_error=False)
     rec = {"workload": f"{geo.name} embed extract, batch={batch} x {seconds:.0f} s, mode={mode}, {inflight} batch(es) in flight x {micro} group(s)",
-           "value": round(utts / dt, 1), "unit": "utterances/s", "steps": steps, "batches_per_step": reps * inflight,
-           "ms_per_batch": round(1e3 * dt / steps / reps / inflight, 3), "gflop_per_utt": round(gf, 1),
-           "achieved_tflops_whole_path": round(utts / dt * gf / 1e3, 1), "frac_of_bf16_peak": round(utts / dt * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
-           "verified": bool(same and finite), "graph_replay_equals_eager_bitwise": bool(same), "all_finite": finite,
-           "weights": "seeded synthetic (fast generator)", "seconds_incl_weight_generation": None}
-    del enc, hs, kept, eager, graph, groups
-    torch.cuda.empty_cache()
+           "gflop_per_utt": round(gf, 1)}
+    rec.update({k: v for k, v in timed.items() if k != "mode"})
+    rec["modes"] = {m: one_mode(m, with_error=True) for m in parity_modes if m != mode}
+    rec["verified"] = bool(rec["verified"] and all(v["verified"] for v in rec["modes"].values()))
+    rec["weights"] = "seeded synthetic (fast generator); errors: worst hidden state of utterance 0 against the fp32 CPU oracle"
+    del sd
     rec["seconds_incl_weight_generation"] = round(time.perf_counter() - t_all, 1)
     return rec
 
@@ -355,9 +375,11 @@ def main():
     ap.add_argument("--e2e-files", type=int, default=4096)
     ap.add_argument("--e2e-default-files", type=int, default=1024,
                     help="files of the second end-to-end leg, run in the drivers' DEFAULT numerics mode (0: skip)")
-    ap.add_argument("--other-encoders", type=str, default="hubert,whisper",
+    ap.add_argument("--other-encoders", type=str, default="xlsr,hubert,whisper",
                     help="after the headline: short verified runs (3 steps) of BASELINE configs[2..4]'s encoders on their own batch "
-                         "shapes, comma separated from xlsr,hubert,whisper ('' or none: skip; xlsr adds ~1 min of weight generation)")
+                         "shapes, in the timed mode AND in the tolerance-grade modes (f16x, f16m: throughput + error against the CPU oracle), "
+                         "comma separated from xlsr,hubert,whisper ('' or none: skip -- what every script under tools/ passes; xlsr adds "
+                         "~1 min of weight generation)")
     ap.add_argument("--e2e-workers", type=int, default=4, help="host threads of the end-to-end leg (reference default 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--split", type=str, default="", help="explicit utterance-group sizes, e.g. 9,7 (overrides --micro)")
@@ -592,7 +614,12 @@ def main():
         out = {
             "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract" if geo is C.WAVLM_LARGE and abs(args.seconds - 10) < 1e-6
                       else f"utterances/sec ({args.seconds:.0f} s @16 kHz) {geo.name} embed extract",
-            "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "utterances/s",
+            # the tolerance-grade figures next to the headline (filled below from `parity_mode`: the drivers' default numerics, and the
+            # fastest mode inside north_star's 1e-3), so that a truncated line still shows them
+            "parity_value": None, "parity_mode_name": None, "parity_err": None,
+            "fast_parity_value": None, "fast_parity_mode_name": None, "fast_parity_err": None,
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_name[args.mode], "data": "synthetic",
@@ -760,8 +787,17 @@ def main():
                 if enc_p is not enc:
                     del enc_p, hs_p
                     torch.cuda.empty_cache()
-            verification["parity_modes_within_1e-3_of_oracle"] = bool(all(
-                v["within_tolerance"] for k, v in out.items() if k.startswith("parity_mode")))
+            precs = [v for k, v in out.items() if k.startswith("parity_mode") and isinstance(v, dict)]
+            verification["parity_modes_within_1e-3_of_oracle"] = bool(all(v["within_tolerance"] for v in precs))
+            if precs:
+                first = out["parity_mode"]
+                out["parity_value"], out["parity_mode_name"], out["parity_err"] = first["value"], first["mode"], first["max_rel_err_vs_oracle"]
+                # ... among the modes that hold the 1e-3 gate at FULL DEPTH under the stress weights too (tests/test_gpu_depth.py): on the
+                # bench's Gaussian weights f16 / f16a are inside 1e-3 as well, under sharp attention at 24 layers they are not
+                ok = [v for v in precs if v["within_tolerance"] and v["mode"] in ("f16x", "f16m", "fp32x")]
+                if ok:
+                    best = max(ok, key=lambda v: v["value"])
+                    out["fast_parity_value"], out["fast_parity_mode_name"], out["fast_parity_err"] = best["value"], best["mode"], best["max_rel_err_vs_oracle"]
         if verification is not None:
             out["verified"] = bool(checks_ok)
             out["verification"] = verification
@@ -773,6 +809,8 @@ def main():
             del enc, hs_timed, groups, packed
             torch.cuda.empty_cache()
             out["other_encoders"] = {n: other_encoder_run(n, device, args.mode) for n in args.other_encoders.split(",") if n in OTHER_ENCODERS}
+            if "verified" in out:                     # a failed check of any encoder fails the line
+                out["verified"] = bool(out["verified"] and all(v["verified"] for v in out["other_encoders"].values()))
         if world == 1 and not args.no_cpu_baseline and not whisper:
             out["cpu_baseline"] = cpu_baseline(geo, sd, num_samples)
         print(json.dumps(out), flush=True)

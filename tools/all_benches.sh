@@ -1,4 +1,4 @@
-run() { python bench.py --no-cpu-baseline --no-trace "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['metric'][:70], '|', d['value'], d['unit'], d['ms_per_step'], 'ms', d.get('achieved_tflops_whole_path'))"; }
+run() { python bench.py --other-encoders none --no-cpu-baseline --no-trace "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['metric'][:70], '|', d['value'], d['unit'], d['ms_per_step'], 'ms', d.get('achieved_tflops_whole_path'))"; }
 run
 run --mode fp32x
 run --ssl_type facebook/hubert-xlarge-ll60k

@@ -17,8 +17,8 @@ done
 for rep in 1 2; do
 for v in head l0 l1; do
   echo "== $v: whisper step (rep $rep)" | tee -a $OUT
-  SER_HIP_LIB=$PWD/interspeech_ser_amd/lib/libserhip_$v.so python bench.py --ssl_type openai/whisper-large-v3 --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d.get('verified'))" | tee -a $OUT
+  SER_HIP_LIB=$PWD/interspeech_ser_amd/lib/libserhip_$v.so python bench.py --other-encoders none --ssl_type openai/whisper-large-v3 --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d.get('verified'))" | tee -a $OUT
   echo "== $v: wavlm step (rep $rep)" | tee -a $OUT
-  SER_HIP_LIB=$PWD/interspeech_ser_amd/lib/libserhip_$v.so python bench.py --no-cpu-baseline --no-parity --no-e2e --no-trace 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d.get('verified'))" | tee -a $OUT
+  SER_HIP_LIB=$PWD/interspeech_ser_amd/lib/libserhip_$v.so python bench.py --other-encoders none --no-cpu-baseline --no-parity --no-e2e --no-trace 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d.get('verified'))" | tee -a $OUT
 done
 done

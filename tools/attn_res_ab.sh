@@ -12,6 +12,6 @@ pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][
 for rep in 1 2; do
 for v in 0 1; do
   echo "== SER_ATTN_RESIDENT=$v step (rep $rep)" | tee -a $OUT
-  SER_ATTN_RESIDENT=$v python bench.py --no-cpu-baseline --no-parity --no-e2e "$@" 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_ATTN_RESIDENT=$v python bench.py --other-encoders none --no-cpu-baseline --no-parity --no-e2e "$@" 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
 done

@@ -10,8 +10,8 @@ pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][
 for rep in 1 2; do
 for v in 0 1; do
   echo "== bf16, SER_GATE_IN_ATTN=$v (rep $rep)" | tee -a $OUT
-  SER_GATE_IN_ATTN=$v python bench.py --no-cpu-baseline --no-parity --no-e2e --no-trace 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_GATE_IN_ATTN=$v python bench.py --other-encoders none --no-cpu-baseline --no-parity --no-e2e --no-trace 2>/dev/null | python -c "$pick" | tee -a $OUT
   echo "== f16a, SER_GATE_IN_ATTN=$v (rep $rep)" | tee -a $OUT
-  SER_GATE_IN_ATTN=$v python bench.py --mode f16a --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_GATE_IN_ATTN=$v python bench.py --other-encoders none --mode f16a --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
 done

@@ -11,6 +11,6 @@ pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][
 for rep in 1 2; do
 for f in "" "1280:1280:0" "1280:1280:1" "1280:5120:2" "1280:5120:0"; do
   echo "== SER_GEMM_FORCE='$f' (rep $rep)" | tee -a $OUT
-  SER_GEMM_FORCE="$f" python bench.py --ssl_type facebook/hubert-xlarge-ll60k --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 5 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_GEMM_FORCE="$f" python bench.py --other-encoders none --ssl_type facebook/hubert-xlarge-ll60k --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 5 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
 done

@@ -12,6 +12,6 @@ for rep in 1 2 3; do
 for v in head new; do
   L=$LIBD/libserhip_$v.so; [ $v = new ] && L=$LIBD/libserhip.so
   echo "== $v (rep $rep) $*" | tee -a $OUT
-  SER_HIP_LIB=$L python bench.py --no-cpu-baseline --no-parity --no-e2e --no-trace "$@" 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_HIP_LIB=$L python bench.py --other-encoders none --no-cpu-baseline --no-parity --no-e2e --no-trace "$@" 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
 done

@@ -10,6 +10,6 @@ pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][
 for rep in 1 2; do
 for n in 0 1; do
   echo "== SER_PINNED_DECODE=$n (rep $rep)" | tee -a $OUT
-  SER_PINNED_DECODE=$n python bench.py --no-cpu-baseline --no-parity --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_PINNED_DECODE=$n python bench.py --other-encoders none --no-cpu-baseline --no-parity --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
 done

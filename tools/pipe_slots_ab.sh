@@ -10,12 +10,12 @@ pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][
 for rep in 1 2; do
 for n in 2 3; do
   echo "== wavlm bf16, SER_PIPE_SLOTS=$n (rep $rep)" | tee -a $OUT
-  SER_PIPE_SLOTS=$n python bench.py --no-cpu-baseline --no-parity --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_PIPE_SLOTS=$n python bench.py --other-encoders none --no-cpu-baseline --no-parity --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
 done
 for n in 2 3; do
   echo "== wavlm f16a, SER_PIPE_SLOTS=$n" | tee -a $OUT
-  SER_PIPE_SLOTS=$n python bench.py --mode f16a --no-cpu-baseline --no-parity --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_PIPE_SLOTS=$n python bench.py --other-encoders none --mode f16a --no-cpu-baseline --no-parity --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
   echo "== whisper bf16, SER_PIPE_SLOTS=$n" | tee -a $OUT
-  SER_PIPE_SLOTS=$n python bench.py --ssl_type openai/whisper-large-v3 --no-cpu-baseline --no-parity --no-trace --steps 5 --e2e-files 1024 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_PIPE_SLOTS=$n python bench.py --other-encoders none --ssl_type openai/whisper-large-v3 --no-cpu-baseline --no-parity --no-trace --steps 5 --e2e-files 1024 2>/dev/null | python -c "$pick" | tee -a $OUT
 done

@@ -13,7 +13,7 @@ FLAGS="--no-trace --no-cpu-baseline --no-parity --no-e2e --other-encoders none"
 stats() {  # name, bench args...
     local name=$1; shift
     rm -rf $OUT/$name                       # rocprofv3 -d accumulates one subdirectory per run: never stamp a stale CSV
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py $FLAGS "$@" > $OUT/$name.json 2> $OUT/$name.err || return 1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 bench.py --other-encoders none $FLAGS "$@" > $OUT/$name.json 2> $OUT/$name.err || return 1
     local f=$(ls -t $OUT/$name/*/*kernel_stats.csv | head -1)
     cp "$f" profiles/${TAG}_kernel_stats_$name.csv
     cp $OUT/$name.json profiles/${TAG}_bench_under_rocprof_$name.json
@@ -23,8 +23,8 @@ stats() {  # name, bench args...
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_l2 $OUT/wpmc_fetch $OUT/wpmc_write
 PMC="--steps 2 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS"
 if [ "$2" = "traffic" ]; then   # only the two traffic passes: re-stamp profiles/<tag>_pmc_traffic.json after a kernel-source change
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --other-encoders none $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --other-encoders none $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
     python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|inflight=2|groups=1"
     mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_pmc_* gpurun_out/profiles_$TAG/
     echo done; exit 0
@@ -40,22 +40,22 @@ stats hubert_xlarge_bf16 --steps 5 --ssl_type facebook/hubert-xlarge-ll60k || ex
 stats xlsr_2b_bf16 --steps 5 --ssl_type facebook/wav2vec2-xls-r-2b --batch 8 || exit 1
 stats whisper_large_v3_bf16 --steps 3 --reps 4 --ssl_type openai/whisper-large-v3 --seconds 30 || exit 1
 # PMC passes: eager launches (counters are per dispatch), headline workload
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --other-encoders none $PMC > /dev/null 2> $OUT/pmc_fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --other-encoders none $PMC > /dev/null 2> $OUT/pmc_write.err || exit 1
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG "microsoft/wavlm-large|bf16|batch=16x10s|inflight=2|groups=1"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
-    --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_sq.err || exit 1
+    --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py --other-encoders none $PMC > /dev/null 2> $OUT/pmc_sq.err || exit 1
 # second SQ pass: what the K loop waits on (LDS issue stalls, vector and matrix instructions executing together)
 rm -rf $OUT/pmc_sq2
 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE \
-    --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_sq2.err || echo "(second SQ pass not available: $(tail -1 $OUT/pmc_sq2.err))"
+    --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py --other-encoders none $PMC > /dev/null 2> $OUT/pmc_sq2.err || echo "(second SQ pass not available: $(tail -1 $OUT/pmc_sq2.err))"
 python3 tools/pmc_sq_summary.py $OUT/pmc_sq profiles/$TAG $OUT/pmc_sq2
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 bench.py $PMC > /dev/null 2> $OUT/pmc_l2.err || exit 1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 bench.py --other-encoders none $PMC > /dev/null 2> $OUT/pmc_l2.err || exit 1
 python3 tools/pmc_l2_summary.py $OUT/pmc_l2 profiles/$TAG
 # Whisper front end alone against HBM bytes (FETCH/WRITE of the logmel kernels come out of the per-kernel CSV)
 WPMC="--steps 1 --warmup 1 --reps 1 --no-graph --no-verify $FLAGS --ssl_type openai/whisper-large-v3 --seconds 30"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_fetch -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_fetch.err || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_write -- python3 bench.py $WPMC > /dev/null 2> $OUT/wpmc_write.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_fetch -- python3 bench.py --other-encoders none $WPMC > /dev/null 2> $OUT/wpmc_fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/wpmc_write -- python3 bench.py --other-encoders none $WPMC > /dev/null 2> $OUT/wpmc_write.err || exit 1
 python3 tools/pmc_summary.py $OUT/wpmc_fetch $OUT/wpmc_write profiles/${TAG}_whisper "openai/whisper-large-v3|bf16|batch=16x30s|inflight=1|groups=2"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/      # profiles/ itself does not travel back
 echo done

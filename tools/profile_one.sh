@@ -8,7 +8,7 @@ OUT=gpurun_out/prof
 mkdir -p $OUT profiles gpurun_out/profiles_$TAG
 export TMPDIR=/tmp
 rm -rf $OUT/$NAME
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$NAME -- python3 bench.py --no-trace --no-cpu-baseline --no-parity --no-e2e "$@" > $OUT/$NAME.json 2> $OUT/$NAME.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$NAME -- python3 bench.py --other-encoders none --no-trace --no-cpu-baseline --no-parity --no-e2e "$@" > $OUT/$NAME.json 2> $OUT/$NAME.err || exit 1
 f=$(ls -t $OUT/$NAME/*/*kernel_stats.csv | head -1)
 cp "$f" profiles/${TAG}_kernel_stats_$NAME.csv
 cp $OUT/$NAME.json profiles/${TAG}_bench_under_rocprof_$NAME.json

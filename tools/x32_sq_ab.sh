@@ -11,10 +11,10 @@ pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][
 for rep in 1 2; do
 for v in 150 100; do
   echo "== f16a, SER_GEMM_X32_SQ_MIN=$v (rep $rep)" | tee -a $OUT
-  SER_GEMM_X32_SQ_MIN=$v python bench.py --mode f16a --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_GEMM_X32_SQ_MIN=$v python bench.py --other-encoders none --mode f16a --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
 done
 for v in 150 100; do
   echo "== fp32x, SER_GEMM_X32_SQ_MIN=$v" | tee -a $OUT
-  SER_GEMM_X32_SQ_MIN=$v python bench.py --mode fp32x --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
+  SER_GEMM_X32_SQ_MIN=$v python bench.py --other-encoders none --mode fp32x --no-cpu-baseline --no-parity --no-e2e --no-trace --steps 10 2>/dev/null | python -c "$pick" | tee -a $OUT
 done
