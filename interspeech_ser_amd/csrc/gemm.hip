@@ -101,7 +101,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define SER_MX_ASM 1
 #endif
 #ifndef SER_MX_FP6_WHATIF
-#define SER_MX_FP6_WHATIF 0       // 1: the cross-term MFMAs read their operands as e2m3 (timing what-if: wrong results, tools/ab)
+#define SER_MX_FP6_WHATIF 0       // 1: the cross-term MFMAs read their operands as e2m3 (timing what-if, WRONG results: profiles/r05_f16m_e2m3_whatif.txt)
 #endif
 typedef __attribute__((ext_vector_type(6))) int i32x6;
 __device__ __forceinline__ void mfma_scale8(f32x4& acc, const i32x8& a, const i32x8& b, int sa, int sb) {
@@ -223,22 +223,6 @@ void ser_gemm_kernel(const ser_gemm_args p) {
         n = n < p.N ? n : p.N - 1;
         woff[q] = (uint32_t)(((int64_t)(n - n0) * p.K + c * 8) * 2);
     }
-#if SER_MX_FP6_WHATIF >= 2
-    // what-if: compact e2m3 cross-term units -- 96 bytes per row and K tile, 48 lanes per DMA piece (8 rows), pieces 784 bytes apart in LDS
-    uint32_t aoffE[LA], woffE[LW];
-#pragma unroll
-    for (int q = 0; q < LA; ++q) {
-        int m = m0 + (q * NW + wave) * 8 + (lane < 48 ? lane / 6 : 0);
-        m = m < p.M ? m : p.M - 1;
-        aoffE[q] = (uint32_t)(((int64_t)m * p.lda - arow0) * 2 + (lane % 6) * 16);
-    }
-#pragma unroll
-    for (int q = 0; q < LW; ++q) {
-        int n = n0 + (q * NW + wave) * 8 + (lane < 48 ? lane / 6 : 0);
-        n = n < p.N ? n : p.N - 1;
-        woffE[q] = (uint32_t)(((int64_t)(n - n0) * p.K) * 2 + (lane % 6) * 16);
-    }
-#endif
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
 
     const int nk = p.K / BK;
@@ -281,15 +265,6 @@ void ser_gemm_kernel(const ser_gemm_args p) {
     };
     auto issue_piece = [&](int j) {                              // j in [0, LPT): plane-major, A pieces then W pieces (compile-time j)
         const int pl = j / (LA + LW), q = j % (LA + LW);
-#if SER_MX_FP6_WHATIF >= 2
-        if (M16 && (i_kk & 1)) {
-            if (lane < 48) {
-                if (q < LA) dma_lds<16>(is_ua, aoffE[q < LA ? q : 0], is_dstA - wave * 1024 + (q * NW + wave) * 784);
-                else dma_lds<16>(is_uw, woffE[q >= LA ? q - LA : 0], is_dstW - wave * 1024 + ((q - LA) * NW + wave) * 784);
-            }
-            return;
-        }
-#endif
         if (q < LA) dma_lds<16>(is_ua + (int64_t)pl * p.a_plane_stride * 2, aoff[q < LA ? q : 0], is_dstA + pl * A_BYTES + q * NW * 1024);
         else dma_lds<16>(is_uw + (int64_t)pl * p.w_plane_stride * 2, woff[q >= LA ? q - LA : 0], is_dstW + pl * W_BYTES + (q - LA) * NW * 1024);
     };
@@ -564,26 +539,6 @@ void ser_gemm_kernel(const ser_gemm_args p) {
                     for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = mfma16<SER_MODE_FP16>(wf[u][ni], af[u][mi], acc[ni][mi]);
         };
         auto e_phase_reads = [&](const char* sb, const unsigned char* scb, int ph, auto& a8, auto& w8, auto& sa, auto& sw) {
-#if SER_MX_FP6_WHATIF >= 2
-            typedef __attribute__((ext_vector_type(2))) int i32x2;
-#pragma unroll
-            for (int x = 0; x < TMP; ++x) {
-                const int row = wm * TM * 16 + (ph * TMP + x) * 16 + frow;
-                const char* src = sb + (row >> 3) * 784 + (row & 7) * 96 + fq * 24;
-                const i32x2 c0 = *(const i32x2*)src, c1 = *(const i32x2*)(src + 8), c2 = *(const i32x2*)(src + 16);
-                a8[x] = (i32x8){c0[0], c0[1], c1[0], c1[1], c2[0], c2[1], 0, 0};
-                sa[x] = scb[(wm * TM * 16 + (ph * TMP + x) * 16 + frow) * 4 + fq];
-            }
-#pragma unroll
-            for (int x = 0; x < TN; ++x) {
-                const int row = wn * TN * 16 + x * 16 + frow;
-                const char* src = sb + A_BYTES + (row >> 3) * 784 + (row & 7) * 96 + fq * 24;
-                const i32x2 c0 = *(const i32x2*)src, c1 = *(const i32x2*)(src + 8), c2 = *(const i32x2*)(src + 16);
-                w8[x] = (i32x8){c0[0], c0[1], c1[0], c1[1], c2[0], c2[1], 0, 0};
-                sw[x] = scb[(BM + wn * TN * 16 + x * 16 + frow) * 4 + fq];
-            }
-            return;
-#endif
 #pragma unroll
             for (int x = 0; x < TMP; ++x) {
                 const int mi = ph * TMP + x;
