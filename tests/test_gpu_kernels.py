@@ -71,6 +71,8 @@ def run_gemm(L, A_act, W_act, M, N, K, mode, **kw):
     g.res_row_mod = kw.get("res_row_mod", 0)
     ncols = kw.get("out_cols", N * g.groups)
     out_f32 = torch.full((kw.get("out_rows", M), ncols), float("nan"), device=DEV) if kw.get("want_f32", True) else None
+    if kw.get("in_place"):                                   # the encoder layers' residual GEMMs write the state they read
+        out_f32 = res
     g.out_f32 = out_f32.data_ptr() if out_f32 is not None else None
     g.ldo_f32 = ncols
     planes = 2 if mode == 2 else 1
@@ -154,6 +156,23 @@ def test_gemm_many_tiles_per_cu_integer_exact(L, cfg):
     ref = A.double() @ W.double().T + bias.double() + res.double()
     out, _ = run_gemm(L, to_act(A, 1), to_act(W, 1), M, N, K, 1, bias=bias.to(DEV), residual=res.to(DEV), ldr=N, tile_cfg=cfg)
     assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("M,N,K,mod", [(1000, 1024, 1024, 0), (515, 392, 512, 0), (700, 264, 576, 0), (300, 256, 448, 0), (600, 384, 640, 100)])
+def test_gemm_residual_in_place_integer_exact(L, M, N, K, mod):
+    """The encoder layers' residual GEMMs write the fp32 state they read (engine.py `_gemm(ctx, out, residual=h, out_f32=h)`): exact integers
+    against fp64 with the residual IN PLACE on the 128x128 and 256x128 tiles, ragged M / N edges, 7 - 16 K tiles, and a row-periodic residual.
+    (Round 5 tried requesting the residual tile during the K loop on these shapes -- slower, DEADENDS.md -- and this is the test it had to pass.)"""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    res = torch.randint(-9, 10, (mod or M, N), generator=g).float()
+    ref = A.double() @ W.double().T + bias.double() + (res.double().repeat(M // mod, 1) if mod else res.double())
+    for cfg in (1, 2):
+        out, _ = run_gemm(L, to_act(A, 1), to_act(W, 1), M, N, K, 1, bias=bias.to(DEV), residual=res.clone().to(DEV), ldr=N, tile_cfg=cfg,
+                          in_place=(mod == 0), res_row_mod=mod)
+        assert torch.equal(out.cpu().double(), ref), cfg
 
 
 def test_gemm_fp32x_large_grid_tile_integer_exact(L):
