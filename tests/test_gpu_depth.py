@@ -23,40 +23,40 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GATE = 1e-3
-CASES = [("wavlm", "sharp2"), ("wavlm", "outliers"), ("wavlm", "lora"),
-         ("hubert", "sharp2")]           # (wavlm rowmean, hubert lora / rowmean / outliers, XLS-R-2B: profiles/r04_depth_envelope*.txt; the suite's time
-                                         # budget -- the CPU oracle's share doubles on a slow box: 581 s / 839 s for the same suite on two boxes)
+# The suite's time budget (round-4 verdict 7c: <= 550 s on a driver box; the CPU oracle and the weight generation are most of a case): the gate
+# cases draw their weights from torch's generator (seconds), run fp32x only where it is cheap (WavLM-large), and leave to the report generator
+# (python tests/depth_envelope.py -> profiles/r04_depth_envelope*.txt, r05_depth_envelope_f16m*.txt) the cases measured there and stable since:
+# WavLM row means, HuBERT LoRA / row means / outliers, XLS-R-2B, and every "f16a" row.
+CASES = [("wavlm", "sharp2"), ("wavlm", "lora"), ("wavlm", "outliers"), ("hubert", "sharp2")]
 
 
 @pytest.mark.parametrize("model,kind", CASES)
 def test_full_depth_stress_envelope(model, kind):
     import depth_envelope as DE
-    modes = ("f16x", "fp32x", "f16m", "f16a") if (model == "wavlm" and kind in ("sharp2", "lora")) else ("f16x", "fp32x", "f16m")
-    res = DE.envelope(model, kind, modes)
+    modes = ("f16x", "fp32x", "f16m") if (model == "wavlm" and kind != "outliers") else ("f16x", "f16m")
+    res = DE.envelope(model, kind, modes, fast=True)
     worst = {k: max(v) for k, v in res.items()}
     print(f"{DE.MODELS[model]} stress={kind}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
-    for mode in ("f16x", "fp32x", "f16m"):               # the parity-grade modes hold north_star's 1e-3 at the depth they ship at
+    for mode in modes:                                   # the parity-grade modes hold north_star's 1e-3 at the depth they ship at
         assert worst[mode] < GATE, (model, kind, mode, worst)
         if kind == "outliers":                           # ... and on the ordinary channels' own scale beside the 800-sized ones
             assert worst[mode + ":ordinary"] < GATE, worst
     assert worst["f16x"] < 2.5e-4, worst                 # the default keeps a 4x margin (measured <= 1.0e-4)
-    assert worst["f16x"] <= worst["fp32x"] * 1.05, worst # 22-bit operands are never worse than 16-bit ones at the same cost
-    assert worst["f16x"] <= worst["f16m"] * 1.05, worst  # ... nor than the ~15-bit ones of the faster mode
-    if model in ("wavlm", "hubert"):
-        assert worst["f16m"] <= worst["fp32x"] * 1.05, worst   # measured: inside fp32x's envelope on the wav2vec2-style encoders
-    if "f16a" in worst:
-        # the documented envelope of the faster mode: parity everywhere except under sharp attention at depth
-        assert worst["f16a"] < (1e-2 if kind == "sharp2" else GATE), worst
+    if kind != "outliers":                               # (there both sit at the shared fp16x stem's 2.8e-6)
+        assert worst["f16x"] <= worst["f16m"] * 1.05, worst  # 22-bit operands are never worse than the ~15-bit ones of the faster mode
+    if "fp32x" in worst:
+        assert worst["f16x"] <= worst["fp32x"] * 1.05, worst   # ... nor than 16-bit ones at the same cost
+        assert worst["f16m"] <= worst["fp32x"] * 1.05, worst   # measured: f16m inside fp32x's envelope on the wav2vec2-style encoders
 
 
 def test_full_depth_whisper_sharp_attention():
     """The Whisper-large-v3 encoder (32 layers, 1 500 frames; preprocessing/preprocess_whisper.py:48-76) under the same stress: q / k
     projections x 2, a full 30 s window alone and a ragged 7.3 s + 30 s pair, the rows the driver saves of all 33 states against
-    oracle.whisper_hidden_states on oracle.whisper_log_mel.  Measured (profiles/r04_depth_envelope_whisper.txt): f16x 5.6e-5, fp32x 3.2e-4
-    (f16a 4.8e-3: outside, like the speech encoders)."""
+    oracle.whisper_hidden_states on oracle.whisper_log_mel.  Measured (profiles/r04_depth_envelope_whisper.txt, r05_depth_envelope_f16m_hubert_whisper.txt):
+    f16x 5.6e-5, fp32x 3.2e-4, f16m 5.7e-4 -- its widest case (1 500 keys per softmax) and the one where it is worse than fp32x; f16a 4.8e-3: outside."""
     import depth_envelope as DE
-    res = DE.whisper_envelope("sharp2", ("f16x", "fp32x", "f16m"))
+    res = DE.whisper_envelope("sharp2", ("f16x", "f16m"), fast=True)
     worst = {k: max(v) for k, v in res.items()}
     print("openai/whisper-large-v3 stress=sharp2: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
-    assert worst["fp32x"] < GATE and worst["f16m"] < GATE, worst          # f16m: 5.7e-4 here, its widest case (1 500 keys per softmax)
-    assert worst["f16x"] < 2.5e-4 and worst["f16x"] <= worst["fp32x"] * 1.05, worst
+    assert worst["f16m"] < GATE, worst
+    assert worst["f16x"] < 2.5e-4 and worst["f16x"] <= worst["f16m"] * 1.05, worst
