@@ -12,7 +12,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interspeech_ser_amd import _lib as L                     # noqa: E402
+_argv, sys.argv = sys.argv, sys.argv[:1]                      # (the module reads its own M from argv at import)
 import gemm_f16m_bench as GB                                  # noqa: E402  (operand packing)
+sys.argv = _argv
 
 SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 MODE = {"bf16": 1, "f16": 3, "f16x": 4, "f16m": 6}[sys.argv[2] if len(sys.argv) > 2 else "bf16"]
