@@ -39,11 +39,13 @@ __global__ __launch_bounds__(512, 2) void probe(const u32x4* __restrict__ seed, 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < LDSB / 16; i += 512) ((u32x4*)lds)[i] = seed[(blockIdx.x * 131 + i) & 65535];
     __syncthreads();
-    constexpr bool WIDE = (VAR == 2 || VAR == 3 || VAR >= 7);
-    constexpr bool DMA = (VAR == 7 || VAR == 8 || VAR == 9);
+    constexpr bool WIDE = (VAR == 2 || VAR == 3 || (VAR >= 7 && VAR <= 10));
+    constexpr bool DMA = (VAR == 7 || VAR == 8 || VAR == 9 || VAR >= 11);
+    constexpr bool DMAONLY = (VAR >= 11);
+    constexpr int NQ = (VAR == 12 || VAR == 13) ? 8 : 4;
     // DMA variants: the block's LDS image is 64 KiB of fragments + a 64 KiB landing zone behind it (never read: the data the MFMAs see stays the seed's)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
-    const size_t sb_ = (size_t)src + (size_t)(VAR == 7 ? 0 : blockIdx.x) * span;
+    const size_t sb_ = (size_t)src + (size_t)((VAR == 7 || VAR == 11 || VAR == 12) ? 0 : blockIdx.x) * span;
     const unsigned sb_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)sb_), sb_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sb_ >> 32));
     const char* sbase = (const char*)(((size_t)sb_hi << 32) | (size_t)sb_lo);
     unsigned doff = (unsigned)(wave * 4096 + lane * 16);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void probe(const u32x4* __restrict__ seed, 
     for (int x = 0; x < NB; ++x) fb[x] = *(const bf16x8*)(lds + ((wave * 4096 + 32768 + x * 1024 + lane * 16) & (LDSB - 1)));
     float sink = 0.f;
     for (int it = 0; it < iters; ++it) {
-        if constexpr (VAR != 4 && VAR != 5) {
+        if constexpr (VAR != 4 && VAR != 5 && !DMAONLY) {
             const int base = ((it * 7 + wave * 5) & 15) * 4096;    // a different window of the block's LDS image every k-step
 #pragma unroll
             for (int x = 0; x < NA; ++x) fa[x] = *(const bf16x8*)(lds + ((base + x * 1024 + lane * 16) & (LDSB - 1)));
@@ -73,14 +75,16 @@ __global__ __launch_bounds__(512, 2) void probe(const u32x4* __restrict__ seed, 
             for (int x = 0; x < NB; ++x) fb[x] = *(const bf16x8*)(lds + ((base + 8192 + x * 1024 + lane * 16) & (LDSB - 1)));
         }
         if constexpr (DMA) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // the previous k-step's four pieces may still fly
+            if constexpr (NQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the previous k-step's pieces may still fly
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dma16(sbase, doff + q * 1024, lds0 + LDSB + wave * 8192 + ((it & 1) * 4 + q) * 1024);
-            doff += 32768;                                         // the block walks its span 32 KiB per k-step (8 waves x 4 KiB)
+            for (int q = 0; q < NQ; ++q) dma16(sbase, doff + q * 1024 + (q >= 4 ? 32768 - 4096 : 0), lds0 + LDSB + wave * 8192 + (NQ == 8 ? q : (it & 1) * 4 + q) * 1024);
+            doff += NQ * 8192;                                     // the block walks its span 32 (64) KiB per k-step (8 waves x 4 (8) KiB)
             if (doff >= span) doff -= span;
         }
         if constexpr (VAR == 10) __builtin_amdgcn_s_barrier();
-        if constexpr (VAR == 6) {
+        if constexpr (DMAONLY) {
+        } else if constexpr (VAR == 6) {
 #pragma unroll
             for (int x = 0; x < NA; ++x) sink += (float)fa[x][0];
 #pragma unroll
@@ -114,7 +118,7 @@ static double now() { timespec t; clock_gettime(CLOCK_REALTIME, &t); return t.tv
 
 template <int VAR>
 static void run(const char* name, double flop_per_iter_per_wave, const u32x4* seed, float* out, double seconds, const char* src = nullptr, unsigned span = 0) {
-    const int LDSB = (VAR == 7 || VAR == 8 || VAR == 9) ? 2 * ::LDSB : ::LDSB;
+    const int LDSB = (VAR == 7 || VAR == 8 || VAR == 9 || VAR >= 11) ? 2 * ::LDSB : ::LDSB;
     const int iters = 20000;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -173,5 +177,10 @@ int main(int argc, char** argv) {
     run<7>("dma_l2", f128, seed, out, seconds, src, 2u << 20);
     run<8>("dma_mall", f128, seed, out, seconds, src, 512u << 10);
     run<9>("dma_hbm", f128, seed, out, seconds, src, 6u << 20);
+    // the fill alone (no MFMAs, no fragment reads): "TF/s" here = what a 256x256 bf16 tile (128 FLOP per byte filled) could run at this fill rate;
+    // bytes per second = TF/s / 128 (dmaonly_4) -- dmaonly_8 moves twice the bytes per iteration: TF/s / 64
+    run<11>("dmaonly_4", f128, seed, out, seconds, src, 2u << 20);
+    run<12>("dmaonly_8", f128, seed, out, seconds, src, 2u << 20);
+    run<13>("dmaonly_8m", f128, seed, out, seconds, src, 512u << 10);
     return 0;
 }
