@@ -299,7 +299,7 @@ def test_config4_extract_train_eval_end_to_end(tmp_path, capsys):
 
 
 @pytest.mark.parametrize("family,mode", [("wavlm", "f16x"), ("hubert", "f16x"), ("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16a"), ("hubert", "f16a"),
-                                         ("wavlm", "f16q"), ("hubert", "f16q"), ("wavlm", "f16")])
+                                         ("wavlm", "f16q"), ("hubert", "f16q"), ("wavlm", "f16"), ("wavlm", "f16m"), ("hubert", "f16m")])
 def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, capsys, family, mode):
     """Next row 8f-4 end to end (preprocessing/preprocess_speech_pretrained.py:108-177): a PEFT-wrapped checkpoint --
     ``wavlm.base_model.model.*`` names, ``q_proj`` / ``v_proj`` split into ``base_layer`` + ``lora_A`` / ``lora_B`` (r = 8,

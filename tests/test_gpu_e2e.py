@@ -241,7 +241,7 @@ def test_too_short_utterance_is_rejected_cleanly():
         enc.forward(enc.upload([np.zeros(399, dtype=np.float32)]), [399])
 
 
-@pytest.mark.parametrize("mode", ["f16x", "fp32x", "f16a", "f16q", "f16", "bf16"])
+@pytest.mark.parametrize("mode", ["f16x", "f16m", "fp32x", "f16a", "f16q", "f16", "bf16"])
 def test_whisper_golden(golden_dir, mode):
     from interspeech_ser_amd import config as C
     from interspeech_ser_amd.engine import WhisperEncoder
