@@ -152,17 +152,21 @@ def is_partial(name: str) -> bool:
 
 
 def stale_partial(save_path: str, name: str, max_age_s: float = 6 * 3600.0) -> bool:
-    """A partial output nobody is writing any more: its writer's pid is gone (same host) or the file has not been touched for hours
-    (another host, or a recycled pid).  ``<path>.tmp`` names of earlier versions count as stale at once."""
+    """A partial output nobody is writing any more: its writer's pid is gone (same host; never within a minute of its last write, so a
+    writer on another host is not taken for a dead one) or the file has not been touched for hours (a recycled pid).  ``<path>.tmp``
+    names of earlier versions count as stale at once."""
     import time
     parts = name.split(".")
     pid = parts[-2] if len(parts) >= 3 and parts[-2].isdigit() else None
     if pid is None:
         return True
     try:
-        if time.time() - os.path.getmtime(os.path.join(save_path, name)) > max_age_s:
-            return True
+        age = time.time() - os.path.getmtime(os.path.join(save_path, name))
     except OSError:
+        return False
+    if age > max_age_s:
+        return True
+    if age < 60.0:                                   # just written: a live writer, possibly on another host where its pid means nothing here
         return False
     if int(pid) == os.getpid():
         return False

@@ -485,14 +485,19 @@ def test_layer_rule_and_resume_do_not_mix_layers_silently(tmp_path, capsys):
         except OSError:
             continue
     (out / f"u2.pt.{dead}.tmp").write_bytes(b"half a file")
+    two_min_ago = __import__("time").time() - 120.0
+    os.utime(out / f"u2.pt.{dead}.tmp", (two_min_ago, two_min_ago))
+    fresh = out / f"u3.pt.{dead}.tmp"                                       # same dead pid, written this very minute: a writer on ANOTHER host
+    fresh.write_bytes(b"half a file")                                       # (its pid means nothing here) -- kept
     # ... and one whose writer is ALIVE (round 5, ADVICE r4: a second job sharing --save_path must not lose its files in progress)
     live = out / f"other_job.pt.{os.getppid()}.tmp"
     live.write_bytes(b"being written by somebody else")
     assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out)], whisper=False, extractor_factory=Stub) == 0
     log = capsys.readouterr().out
     assert "It has 0 files in it" in log and "Layer rule: hidden_states[0]" in log and "WARNING" not in log
-    assert log.count("Removed stale partial output") == 3 and live.exists()
+    assert log.count("Removed stale partial output") == 3 and live.exists() and fresh.exists()
     live.unlink()
+    fresh.unlink()
     assert sorted(os.listdir(out)) == ["u0.pt", "u1.pt", "u2.pt"] and float(torch.load(out / "u1.pt")[0, 0]) == 0.0
     os.remove(out / "u2.pt")                                                # "a killed run": two of three outputs exist
     assert driver._run(["--wav_dir", str(wav_dir), "--save_path", str(out), "--skip_existing"], whisper=False, extractor_factory=Stub) == 0
