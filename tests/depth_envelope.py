@@ -29,6 +29,9 @@ MODELS = {"wavlm": "microsoft/wavlm-large", "hubert": "facebook/hubert-xlarge-ll
 KINDS = ("plain", "sharp2", "sharp2.5", "sharp4", "outliers", "rowmean", "lora")
 
 
+_BASE_SD: dict = {}
+
+
 def rel_err(got, ref):
     return float((got.double() - ref.double()).abs().max() / max(1.0, float(ref.abs().max())))
 
@@ -63,7 +66,10 @@ def case_state_dicts(geo, kind, seed=0, fast=False):
     """fast: torch's generator instead of the host-stable numpy stream (seconds instead of 4 - 13 s per geometry; the suite's gate cases use
     it -- they assert inequalities with measured margins, not recorded numbers; the report generator keeps the stable stream)."""
     from interspeech_ser_amd.weights import apply_stress, synthetic_state_dict
-    sd = synthetic_state_dict(geo, seed, fast=fast)
+    key = (geo.family, geo.hidden, geo.num_layers, geo.heads, tuple(geo.conv_dim), seed, fast)
+    if _BASE_SD.get("key") != key:                   # the last base draw is kept (the suite's WavLM cases share it; every case below copies what it edits)
+        _BASE_SD["key"], _BASE_SD["sd"] = key, synthetic_state_dict(geo, seed, fast=fast)
+    sd = dict(_BASE_SD["sd"])
     if kind == "plain":
         return sd, sd
     if kind == "lora":
