@@ -673,6 +673,9 @@ def main():
                 "clock_note": "peak is the nominal 2.4 GHz figure; a diagnostic build (tools/gemm_clock.py, profiles/r02_gemm_inkernel_clock.txt) "
                               "stamps 1.92-1.97 GHz held inside the 256x256 K loop on random operands, where it runs at 69-73 % of the matrix "
                               "pipe at that clock; not measured in this run",
+                "board_note": "not measured in this run: tools/energy_probe.hip (profiles/r05_energy_probe.txt) -- the matrix pipe alone, register "
+                              "operands, all 256 CUs, sustains 2 220-2 290 TFLOP/s at 1 340-1 370 W of this board's 1 400 W (sclk ~2.2 GHz), a loop of "
+                              "the 256x256 tile's shape with LDS fragment reads and L2 -> LDS fills 1 596; `peak` stays the nominal figure",
             }
         if decomp:
             ms_batch = 1e3 * elapsed / args.steps / reps / inflight
@@ -696,7 +699,7 @@ def main():
                 # durations EXCEEDS the batch time, so it cannot be the step's figure (round-3 verdict, weak #6)
                 r["one_launch_at_a_time"] = {"achieved": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"],
                                              "gemm_ms_per_batch": r["gemm_ms_per_batch"], "measured": r["measured"],
-                                             "rocprof": "profiles/r04_kernel_trace_one_launch_at_a_time_wavlm_large_bf16.csv (same command with "
+                                             "rocprof": "profiles/r05_kernel_trace_one_launch_at_a_time_wavlm_large_bf16.csv (same command with "
                                                         "--no-graph --inflight 1 --micro 1)"}
                 r["achieved"], r["frac"] = round(ach_c, 1), round(ach_c / MFMA_BF16_PEAK_TFLOPS, 4)
                 r["gemm_ms_per_batch"] = decomp["gemm"]["ms_per_batch"]
