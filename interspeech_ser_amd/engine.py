@@ -30,7 +30,11 @@ from ._lib import GemmArgs, check, lib
 from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPER
 
 MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16,
-         "f16x": _lib.MODE_FP16X, "f16m": _lib.MODE_FP16M}
+         "f16x": _lib.MODE_FP16X, "f16m": _lib.MODE_FP16M, "f16mf": _lib.MODE_FP16M}
+# "f16mf" (round 5): "f16m" on the FEED-FORWARD pair only -- FC1 and FC2 (2/3 of the layer FLOPs) multiply in SER_MODE_FP16M, the packed
+# projection, ser_attention and the output projection keep "f16x"'s three products on fp16 hi + lo planes.  oracle/numerics_whatif_f16m.py
+# (sites): under sharp attention the error of "f16m" comes from the packed projection (4.3e-4 of its 5.2e-4 at 24 layers); on FC1 + FC2 alone
+# the same operand format gives 1.4e-4 (sharp x2), 2.7e-5 (LoRA), 1.3e-5 (plain) -- inside "fp32x"'s on each.
 # "f16m" (round 5): the encoder layers' GEMMs on SER_MODE_FP16M operands -- fp16 main product + block-scaled e4m3 cross terms on gfx950's
 # v_mfma_scale_f32_16x16x128_f8f6f4: 2 product-equivalents per algorithmic FLOP instead of "f16x"'s 3 (include/ser_hip.h).  The packed
 # projection, FC1 and FC2 multiply in it; ser_attention and the output projection (8 % of the layer FLOPs, its A operand is the attention
@@ -246,13 +250,13 @@ class _EncoderBase:
         # planes (22-bit operands, round 3) rather than bf16 hi + lo (16-bit, the "fp32x" mode's): same cost, and the stem's share of the error
         # -- which sharp attention amplifies like any other -- drops by the 6 extra bits per operand
         self.stem_mode = (_lib.MODE_FP16X if _STEM_F16X else _lib.MODE_FP32X) if mode in ("f16", "f16q", "f16a") else self.mode
-        if mode == "f16m":
+        if mode in ("f16m", "f16mf"):
             self.stem_mode = _lib.MODE_FP16X
         # WavLM gate inside ser_attention (see the note at the top).  "f16m": as 2H columns of the packed projection instead -- the in-kernel form
         # multiplies the layer input's operand copy, whose second plane is e4m3 bytes in that mode
         self.gate_in_attn = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1" and mode != "f16m"
         self.qk_mode = _lib.MODE_FP16X if mode == "f16q" else None             # logit path on its own launch (None: one packed launch)
-        self.attn_mode = _lib.MODE_FP16X if mode in ("f16a", "f16m") else self.mode   # attention kernel, context rows, output projection
+        self.attn_mode = _lib.MODE_FP16X if mode in ("f16a", "f16m", "f16mf") else self.mode   # attention kernel, context rows, output projection
         self.qkv_mode = _lib.MODE_FP16M if mode == "f16m" else self.attn_mode  # packed projection
         self.x_mode = self.qk_mode or self.qkv_mode                            # format of the operand copy the packed projection reads
         self.qkv_out_mode = self.attn_mode if mode == "f16m" else self.x_mode  # format of q, k, v (what ser_attention reads)
@@ -265,7 +269,7 @@ class _EncoderBase:
         # (packed QKV projection -> attention -> output projection): bench.py's "attention_block" figure
         self.block_trace: Optional[list] = None
         # operand copies with fp16's range: the guard word is live (SER_NO_RANGE_GUARD=1: A/B knob for tools/, never the drivers)
-        self.fp16_planes = mode in ("f16x", "f16m", "f16a", "f16q", "f16") and _os.environ.get("SER_NO_RANGE_GUARD", "0") != "1"
+        self.fp16_planes = mode in ("f16x", "f16m", "f16mf", "f16a", "f16q", "f16") and _os.environ.get("SER_NO_RANGE_GUARD", "0") != "1"
         self._flag: Optional[int] = None    # device address of the range-guard word of the slot being launched / recorded
         self._st: Optional[int] = None      # launch stream of the forward in progress (looked up once per forward)
         self._rec: Optional[Tape] = None    # when set, the launch helpers record into it instead of launching
@@ -804,7 +808,7 @@ class SpeechEncoder(_EncoderBase):
         # 128 x 120 = 15 360-long sums do feel fp16 operands (7.0e-4 -> 8.3e-4 at full geometry), so they stay on the stem format.
         # "f16q" / "f16a" keep it on the stem format always: an error in hidden_states[0] enters layer 0's logits, and these modes
         # exist for attention maps sharp enough to amplify it (LoRA stress fixture: 1.4e-3 -> see DESIGN.md section 4)
-        self.pos_in_stem = (self.mode_name == "f16" and Cg * k > 128 * 80) or self.mode_name in ("f16q", "f16a", "f16m")
+        self.pos_in_stem = (self.mode_name == "f16" and Cg * k > 128 * 80) or self.mode_name in ("f16q", "f16a", "f16m", "f16mf")
         self.pos = self._linear(wp.reshape(G * Cg, k * self.pos_kc), sd["encoder.pos_conv_embed.conv.bias"], stem=self.pos_in_stem)
         self.enc_ln = self._ln_pair(sd, "encoder.layer_norm")
         self.layers = []
@@ -1253,7 +1257,7 @@ class TextEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != FAMILY_ROBERTA:
             raise ValueError("TextEncoder needs a roberta geometry")
-        if mode in ("f16", "f16q", "f16a", "f16m"):
+        if mode in ("f16", "f16q", "f16a", "f16m", "f16mf"):
             raise ValueError("the text encoders support the bf16, fp32x and f16x numerics modes")
         sd = state_dict
         D = geo.hidden
@@ -1368,7 +1372,7 @@ class DebertaEncoder(_EncoderBase):
         super().__init__(geo, device, mode)
         if geo.family != "deberta":
             raise ValueError("DebertaEncoder needs a deberta geometry")
-        if mode in ("f16", "f16q", "f16a", "f16m"):
+        if mode in ("f16", "f16q", "f16a", "f16m", "f16mf"):
             raise ValueError("the text encoders support the bf16, fp32x and f16x numerics modes")
         if geo.head_dim != 64:
             raise ValueError("DeBERTa path: head dim must be 64 (K of the position GEMMs; deberta-v3 base/large have 64)")

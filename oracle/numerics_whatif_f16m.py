@@ -140,7 +140,8 @@ def main():
         print(f"{DE.MODELS[model]} [{kind}], {h0.shape[0]} frames, {geo.num_layers} layers; error of the worst state against exact fp64 layers")
         variants = [("f16x", None), ("bf16x3", None), ("f16m8", None), ("f16m6", None), ("f16", ("fc1", "fc2")), ("f16", None)]
         if len(sys.argv) > 4:
-            variants = [(v, None) for v in sys.argv[4].split(",")]
+            # "f16m8@fc1+fc2": the arithmetic on those GEMMs only, fp16 hi + lo planes (f16x) on the others
+            variants = [(v.split("@")[0], tuple(v.split("@")[1].split("+")) if "@" in v else None) for v in sys.argv[4].split(",")]
         for arith, sites in variants:
             got = layers(geo, ref_sd, h0, arith) if sites is None else layers(geo, ref_sd, h0, arith, sites)
             per = [float((a - b).abs().max() / max(1.0, float(b.abs().max()))) for a, b in zip(got, exact)]

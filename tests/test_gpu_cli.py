@@ -299,7 +299,7 @@ def test_config4_extract_train_eval_end_to_end(tmp_path, capsys):
 
 
 @pytest.mark.parametrize("family,mode", [("wavlm", "f16x"), ("hubert", "f16x"), ("wavlm", "fp32x"), ("hubert", "fp32x"), ("wavlm", "f16a"), ("hubert", "f16a"),
-                                         ("wavlm", "f16q"), ("hubert", "f16q"), ("wavlm", "f16"), ("wavlm", "f16m"), ("hubert", "f16m")])
+                                         ("wavlm", "f16q"), ("hubert", "f16q"), ("wavlm", "f16"), ("wavlm", "f16m"), ("hubert", "f16m"), ("wavlm", "f16mf"), ("hubert", "f16mf")])
 def test_lora_checkpoint_through_the_driver_matches_unmerged_oracle(tmp_path, capsys, family, mode):
     """Next row 8f-4 end to end (preprocessing/preprocess_speech_pretrained.py:108-177): a PEFT-wrapped checkpoint --
     ``wavlm.base_model.model.*`` names, ``q_proj`` / ``v_proj`` split into ``base_layer`` + ``lora_A`` / ``lora_B`` (r = 8,
@@ -391,7 +391,7 @@ def test_fp16_range_guard_fails_the_files_instead_of_clipping(tmp_path, capsys):
     try:
         out = tmp_path / "pt_f16x"
         assert driver.run_speech(["--ssl_type", "tiny-range-test", "--wav_dir", str(wav_dir), "--save_path", str(out), "--checkpoint", str(ck),
-                                  "--use_n_layer", "--n_layer", "-1"]) == 0                      # default mode: f16x
+                                  "--use_n_layer", "--n_layer", "-1"]) == 0                      # default mode: f16mf
         log = capsys.readouterr().out
         assert log.count("Failed to process") == 3 and "fp16 operand range" in log and "--mode fp32x" in log, log
         assert os.listdir(out) == []
@@ -411,7 +411,7 @@ def test_fp16_range_guard_sees_the_feed_forward_intermediate(tmp_path, capsys):
     the row kernels'), read back with every batch.  A checkpoint whose FC1 / GELU output leaves the fp16 range while every hidden state
     stays far below it -- intermediate_dense scaled up by 3e4, output_dense down by the same factor, so the residual stream is the
     unscaled one -- passed round 4's watch (max |hidden state| on sampled batches) and wrote features computed from saturated operands.
-    Now all files of such a batch fail with the --mode fp32x hint in the fp16-plane modes (f16x default, f16m), and extract in fp32x;
+    Now all files of such a batch fail with the --mode fp32x hint in the fp16-plane modes (f16mf default, f16x, f16m), and extract in fp32x;
     the same checkpoint scaled by 1e4 (beyond half the range only) extracts with the one-line warning.
     Contract: preprocessing/preprocess_speech.py:46,72-73 -- a bad file is a printed failure, never silent garbage."""
     from safetensors.torch import save_file
@@ -438,7 +438,7 @@ def test_fp16_range_guard_sees_the_feed_forward_intermediate(tmp_path, capsys):
     C._REGISTRY["tiny-range-test"] = geo
     try:
         ck = checkpoint(3.0e4, "ffn_huge.safetensors")
-        for mode in ("f16x", "f16m"):
+        for mode in ("f16mf", "f16x", "f16m"):
             out = tmp_path / f"pt_{mode}"
             assert driver.run_speech(["--ssl_type", "tiny-range-test", "--wav_dir", str(wav_dir), "--save_path", str(out), "--checkpoint", str(ck),
                                       "--use_n_layer", "--n_layer", "-1", "--mode", mode]) == 0
