@@ -26,10 +26,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GATE = 1e-3
-# The suite's time budget (round-4 verdict 7c: <= 550 s on a driver box; the CPU oracle and the weight generation are most of a case): the gate
-# cases run fp32x only where it is cheap (WavLM-large) and leave to the report generator (python tests/depth_envelope.py ->
-# profiles/r04_depth_envelope*.txt, r05_depth_envelope_f16m*.txt) the cases measured there and stable since: WavLM row means, HuBERT LoRA /
-# row means / outliers, XLS-R-2B, every "f16a" row, and fp32x on HuBERT-xlarge / Whisper-large-v3.  The weights stay the host-stable numpy
+# The suite's time budget (round-4 verdict 7c: <= 550 s on a driver box; the CPU oracle and the weight generation are most of a case): every gate
+# case runs the default ("f16mf") and "f16x"; "fp32x" only on WavLM sharp x2, "f16m" on WavLM sharp x2 / LoRA and Whisper.  The report generator
+# (python tests/depth_envelope.py -> profiles/r04_depth_envelope*.txt, r05_depth_envelope_f16m*.txt, r05_depth_envelope_f16mf.txt) holds the rest,
+# measured there and stable since: WavLM row means, HuBERT LoRA / row means / outliers, XLS-R-2B, every "f16a" row, fp32x and f16m on the
+# other cases.  The weights stay the host-stable numpy
 # stream: with torch's generator (seconds faster) the LoRA case lands on a worse-conditioned draw (fp32x 1.06e-3, f16m 7.6e-4, f16x 1.5e-4
 # against 7.4e-4 / 4.2e-4 / 1.0e-4 here) -- the envelope is a property of the checkpoint as much as of the mode, which is why the default
 # keeps a 4x margin.
@@ -39,7 +40,7 @@ CASES = [("wavlm", "sharp2"), ("wavlm", "lora"), ("wavlm", "outliers"), ("hubert
 @pytest.mark.parametrize("model,kind", CASES)
 def test_full_depth_stress_envelope(model, kind):
     import depth_envelope as DE
-    modes = ("f16x", "fp32x", "f16m", "f16mf") if (model == "wavlm" and kind != "outliers") else ("f16x", "f16m", "f16mf")
+    modes = {("wavlm", "sharp2"): ("f16x", "fp32x", "f16m", "f16mf"), ("wavlm", "lora"): ("f16x", "f16m", "f16mf")}.get((model, kind), ("f16x", "f16mf"))
     res = DE.envelope(model, kind, modes)
     worst = {k: max(v) for k, v in res.items()}
     print(f"{DE.MODELS[model]} stress={kind}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
@@ -47,11 +48,13 @@ def test_full_depth_stress_envelope(model, kind):
         assert worst[mode] < GATE, (model, kind, mode, worst)
         if kind == "outliers":                           # ... and on the ordinary channels' own scale beside the 800-sized ones
             assert worst[mode + ":ordinary"] < GATE, worst
-    assert worst["f16x"] < 2.5e-4, worst                 # the default keeps a 4x margin (measured <= 1.0e-4)
-    if kind != "outliers":                               # (there both sit at the shared fp16x stem's 2.8e-6)
-        assert worst["f16x"] <= worst["f16m"] * 1.05, worst  # 22-bit operands are never worse than the ~15-bit ones of the faster mode
-    # "f16mf" (f16m's operand format on FC1 / FC2 only, round 5): measured 1.75e-4 / 9.1e-5 / 2.8e-6 / 1.2e-4 on these cases -- the 4x margin too
-    assert worst["f16mf"] < 2.5e-4 and worst["f16mf"] <= worst["f16m"] * 1.05, worst
+    assert worst["f16x"] < 2.5e-4, worst                 # round 4's default keeps a 4x margin (measured <= 1.0e-4)
+    # "f16mf", the default (f16m's operand format on FC1 / FC2 only, round 5): measured 1.75e-4 / 9.1e-5 / 2.8e-6 / 1.2e-4 on these cases -- 4x too
+    assert worst["f16mf"] < 2.5e-4, worst
+    if kind != "outliers":                               # (there all sit at the shared fp16x stem's 2.8e-6)
+        assert worst["f16x"] <= worst["f16mf"] * 1.25, worst  # 22-bit operands everywhere vs ~15-bit ones in the feed-forward (XLS-R LoRA: 3.9e-5 / 3.5e-5)
+    if "f16m" in worst:
+        assert worst["f16mf"] <= worst["f16m"] * 1.05, worst  # ... which are never worse than ~15-bit ones in the packed projection too
     if "fp32x" in worst:
         assert worst["f16mf"] <= worst["fp32x"] * 1.05, worst
         assert worst["f16x"] <= worst["fp32x"] * 1.05, worst   # ... nor than 16-bit ones at the same cost
