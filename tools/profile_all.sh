@@ -29,10 +29,15 @@ if [ "$2" = "traffic" ]; then   # only the two traffic passes: re-stamp profiles
     mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_pmc_* gpurun_out/profiles_$TAG/
     echo done; exit 0
 fi
-PART=${2:-all}       # all | stats | pmc | traffic  (stats and pmc as two gpurun calls when one call's limit is too short for both)
+PART=${2:-all}       # all | stats | pmc | traffic | default (= the default mode's kernel stats only)  (stats and pmc as two gpurun calls when one call's limit is too short for both)
+if [ "$PART" = "default" ]; then
+    stats wavlm_large_f16mf --steps 10 --mode f16mf || exit 1
+    mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_*f16mf* gpurun_out/profiles_$TAG/; echo done; exit 0
+fi
 if [ "$PART" != "pmc" ]; then
 stats wavlm_large_bf16 --steps 10 || exit 1
 stats wavlm_large_f16x --steps 10 --mode f16x || exit 1
+stats wavlm_large_f16mf --steps 10 --mode f16mf || exit 1     # the drivers' default (round 5)
 stats wavlm_large_f16m --steps 10 --mode f16m || exit 1
 stats wavlm_large_f16a --steps 10 --mode f16a || exit 1
 # one launch at a time (no graph, one batch, no concurrent branch): the CSV from which roofline.one_launch_at_a_time.avg_launch_us can be
