@@ -546,7 +546,7 @@ def build_text_parser() -> argparse.ArgumentParser:
     p.add_argument("--use_average", type=str, default="n")
     p.add_argument("--batch_size", type=int, default=64)
     p.add_argument("--mode", type=str, default="f16x", choices=["f16x", "fp32x", "bf16"],
-                   help="numerics: f16x (default, as in the speech drivers: 3-product split on fp16 hi + lo planes; 5e-6 of the fp32 reference on Gaussian "
+                   help="numerics: f16x (default: the speech drivers' 3-product split on fp16 hi + lo planes; 5e-6 of the fp32 reference on Gaussian "
                         "weights, 2-5e-5 under sharp attention at 24 layers; values must stay below 65 504 -- checked per batch), fp32x (the same split on "
                         "bf16 planes: fp32 range, 2e-5 / 2-3e-4), bf16 (1e-2)")
     p.add_argument("--checkpoint", type=str, default="")
