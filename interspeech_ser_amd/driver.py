@@ -145,6 +145,11 @@ class _Extractor:
         if D.broadcast_int(1 if (rank == 0 and sd is None) else 0) == 1:
             raise OSError(err or "rank 0 found no checkpoint")
         sd, self.bcast_s, self.bcast_bytes = D.broadcast_state_dict(sd)
+        if args.mode in ("f16mf", "f16m") and (self.geo.hidden % 64 or self.geo.ffn % 64):
+            # the block-scaled cross-term format works on 64-deep K tiles: a geometry whose widths are not multiples of 64 (none of the
+            # reference's four) runs the 3-product split everywhere instead -- same or better parity, ~10 % slower
+            print(f"--mode {args.mode} needs hidden / feed-forward widths that are multiples of 64 (here {self.geo.hidden} / {self.geo.ffn}): using f16x")
+            args.mode = "f16x"
         self.enc = build_encoder(self.geo, sd, device, args.mode)
         del sd                                                # the fp32 broadcast bucket (views of it) is not needed any more
         if torch.cuda.is_available():
