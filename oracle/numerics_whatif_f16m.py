@@ -11,6 +11,10 @@ Candidate arithmetics of  y = x W^T  (x, W in fp64; every one accumulates exactl
              (the OCP MX block format the gfx950 v_mfma_scale_f32_16x16x128_f8f6f4 instruction consumes)
     f16m6    the same with e2m3 (fp6) cross-term planes
 The attention core (q, k, v, P, context rows) keeps fp16 hi + lo planes in the f16m variants, as the HIP path's ser_attention does.
+A fifth argument lists variants as arith@site+site...: sites q, k, v (qkv = all three), out, fc1, fc2 take the arithmetic, the others stay f16x;
+"pv1" puts P and V of the context product on ONE fp16 plane each.  Round 5, WavLM-large, 5 s, worst state (sharp x2 / LoRA): f16m8 everywhere
+5.2e-4 / 4.7e-4; @qkv 4.3e-4 / 4.4e-4; @fc1+fc2 1.4e-4 / 2.7e-5 (= the "f16mf" mode, the drivers' default); @fc1+fc2+out 1.9e-4 / 1.7e-4;
+@fc1+fc2+v 1.8e-4 / 1.5e-4; @fc1+fc2+q 3.2e-4 / 3.0e-4; @fc1+fc2+k 3.5e-4 / 3.4e-4; @fc1+fc2+pv1 3.5e-3 / 3.5e-3; f16x 2.1e-5 / 1.6e-5; bf16x3 1.9e-4 / 2.4e-4.
 Error form of the tests: max|a - b| / max(1, max|b|) per hidden state, worst state, against the all-exact fp64 run.
 Follows HF modeling_wavlm.py:147-241,288-295,355-373 (reference call site preprocessing/preprocess_speech.py:50,66) through oracle.ssl_oracle."""
 import os
@@ -74,7 +78,8 @@ def mm(x, W, arith):
 
 def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
     """sites: which GEMMs run `arith`; the others and the attention core run fp16 hi + lo planes ('f16x')."""
-    A = lambda site: arith if site in sites else "f16x"                    # noqa: E731
+    # site names: "qkv" (= "q", "k", "v" together), "out", "fc1", "fc2"; "pv1": P and V of the context product on ONE fp16 plane each
+    A = lambda site: arith if (site in sites or (site in ("q", "k", "v") and "qkv" in sites)) else "f16x"    # noqa: E731
     eps, H, dh, D = geo.layer_norm_eps, geo.heads, geo.head_dim, geo.hidden
     sd = {k: v.double() for k, v in sd.items()}
     h = h0.double()
@@ -102,10 +107,12 @@ def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
                     Wq = Wq + delta
                 else:
                     Wv = Wv + delta
-        q = deferred_ln_linear(h, p + ".layer_norm", Wq, bq, "qkv") * dh ** -0.5
-        k = deferred_ln_linear(h, p + ".layer_norm", Wk, bk, "qkv")
-        v = deferred_ln_linear(h, p + ".layer_norm", Wv, bv, "qkv")
-        qh, kh, vh = (O._heads(core(t), H) for t in (q, k, v))
+        q = deferred_ln_linear(h, p + ".layer_norm", Wq, bq, "q") * dh ** -0.5
+        k = deferred_ln_linear(h, p + ".layer_norm", Wk, bk, "k")
+        v = deferred_ln_linear(h, p + ".layer_norm", Wv, bv, "v")
+        pv1 = "pv1" in sites and arith != "exact"
+        qh, kh = (O._heads(core(t), H) for t in (q, k))
+        vh = O._heads(r16(v) if pv1 else core(v), H)
         scores = qh @ kh.transpose(1, 2)
         if geo.family == "wavlm":
             x_ln = F.layer_norm(h, (D,), sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"], eps)
@@ -113,7 +120,7 @@ def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
             idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None]) + (T - 1)
             scores = scores + gate[:, :, None] * table[:, idx]
         P = torch.softmax(scores, dim=-1)
-        ctx = (core(P) @ vh).permute(1, 0, 2).reshape(T, D)
+        ctx = ((r16(P) if pv1 else core(P)) @ vh).permute(1, 0, 2).reshape(T, D)
         h = h + mm(ctx, sd[a + ".out_proj.weight"], A("out")) + sd[a + ".out_proj.bias"]
         f = F.gelu(deferred_ln_linear(h, p + ".final_layer_norm", sd[p + ".feed_forward.intermediate_dense.weight"],
                                       sd[p + ".feed_forward.intermediate_dense.bias"], "fc1"))
