@@ -15,6 +15,8 @@ A fifth argument lists variants as arith@site+site...: sites q, k, v (qkv = all 
 "pv1" puts P and V of the context product on ONE fp16 plane each.  Round 5, WavLM-large, 5 s, worst state (sharp x2 / LoRA): f16m8 everywhere
 5.2e-4 / 4.7e-4; @qkv 4.3e-4 / 4.4e-4; @fc1+fc2 1.4e-4 / 2.7e-5 (= the "f16mf" mode, the drivers' default); @fc1+fc2+out 1.9e-4 / 1.7e-4;
 @fc1+fc2+v 1.8e-4 / 1.5e-4; @fc1+fc2+q 3.2e-4 / 3.0e-4; @fc1+fc2+k 3.5e-4 / 3.4e-4; @fc1+fc2+pv1 3.5e-3 / 3.5e-3; f16x 2.1e-5 / 1.6e-5; bf16x3 1.9e-4 / 2.4e-4.
+`... stem [model] [seconds]`: the conv stem's layers 1-6 in each format behind exact layers -- last hidden state under sharp x2 (3 s): f16x 6.6e-5,
+bf16x3 6.2e-4, f16m8 1.4e-3 (outside the gate: every stem error passes through all 24 softmax layers -- the stem stays on 22-bit operands).
 Error form of the tests: max|a - b| / max(1, max|b|) per hidden state, worst state, against the all-exact fp64 run.
 Follows HF modeling_wavlm.py:147-241,288-295,355-373 (reference call site preprocessing/preprocess_speech.py:50,66) through oracle.ssl_oracle."""
 import os
@@ -129,7 +131,59 @@ def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
     return states
 
 
+def stem(geo, sd, x, arith, from_layer=1):
+    """The conv feature encoder in fp64 with the operand roundings of `arith` on conv layers >= from_layer (layer 0, K = 10 taps, and the others
+    stay f16x): each layer as windows [T_out, k * C_in] (frame-major, channel-minor: the order the HIP path's implicit GEMM reads) times
+    W [C_out, k * C_in]^T, then LayerNorm(C) + exact GELU.  Follows oracle.ssl_oracle.conv_feature_encoder (HF modeling_wavlm.py:696-782)."""
+    sd = {k: v.double() for k, v in sd.items() if k.startswith("feature_extractor")}
+    h = x.double()[:, None]                                                  # [L, 1]
+    for i, (k, st) in enumerate(zip(geo.conv_kernel, geo.conv_stride)):
+        p = f"feature_extractor.conv_layers.{i}"
+        W = sd[p + ".conv.weight"]                                           # [C_out, C_in, k]
+        T_out = (h.shape[0] - k) // st + 1
+        idx = (torch.arange(T_out)[:, None] * st + torch.arange(k)[None, :])  # [T_out, k]
+        win = h[idx].reshape(T_out, -1)                                      # [T_out, k * C_in]
+        Wm = W.permute(0, 2, 1).reshape(W.shape[0], -1)                      # [C_out, k * C_in]
+        a = arith if (i >= from_layer and arith != "exact") else ("exact" if arith == "exact" else "f16x")
+        if a in ("f16m8", "f16m6") and win.shape[1] % 32:
+            a = "f16x"
+        y = mm(win, Wm, a)
+        if p + ".conv.bias" in sd:
+            y = y + sd[p + ".conv.bias"]
+        y = F.layer_norm(y, (y.shape[1],), sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"], 1e-5)
+        h = F.gelu(y)
+    return h
+
+
+def main_stem():
+    """python oracle/numerics_whatif_f16m.py stem [wavlm] [seconds]: error of the conv stem's output (and of hidden_states[L] behind exact layers
+    fed with it) when conv layers 1..6 multiply in f16m's format instead of f16x's."""
+    import depth_envelope as DE
+    model = sys.argv[2] if len(sys.argv) > 2 else "wavlm"
+    seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0
+    geo = C.geometry_for(DE.MODELS[model])
+    for kind in ("plain", "sharp2"):
+        ref_sd, _ = DE.case_state_dicts(geo, kind)
+        base = {k: v for k, v in ref_sd.items() if "lora" not in k}
+        with torch.no_grad():
+            x = torch.from_numpy(O.zero_mean_unit_var(DE.clip(101, seconds)))
+            feats = {a: stem(geo, base, x, a) for a in ("exact", "f16x", "bf16x3", "f16m8")}
+            print(f"{DE.MODELS[model]} [{kind}] conv stem, {feats['exact'].shape[0]} frames: error of the stem output / of the last hidden state behind exact layers")
+            outs = {}
+            for a, f in feats.items():
+                h0 = O.feature_projection(geo, base, f.float()).double()
+                h0 = h0 + O.positional_conv(geo, base, h0.float()).double()
+                outs[a] = layers(geo, ref_sd, h0, "exact")
+            for a in ("f16x", "bf16x3", "f16m8"):
+                e0 = float((feats[a] - feats["exact"]).abs().max() / max(1.0, float(feats["exact"].abs().max())))
+                eL = max(float((g - b).abs().max() / max(1.0, float(b.abs().max()))) for g, b in zip(outs[a], outs["exact"]))
+                print(f"  stem layers 1-6 in {a:7s}: stem output {e0:.2e}   worst hidden state {eL:.2e}")
+                sys.stdout.flush()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "stem":
+        return main_stem()
     import depth_envelope as DE
     model = sys.argv[1] if len(sys.argv) > 1 else "wavlm"
     kind = sys.argv[2] if len(sys.argv) > 2 else "sharp2"
