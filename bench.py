@@ -611,7 +611,7 @@ def main():
                       "f16q": "f16 (f16x3 stem and logit path)", "f16a": "f16 (f16x3 stem and attention block)",
                       "f16x": "f16x3 (fp16 hi + lo planes, 3 products)",
                       "f16m": "f16 + block-scaled e4m3 cross terms (2 product-equivalents; f16x3 stem, attention, output projection)",
-                      "f16mf": "f16x3, FC1 / FC2 as f16 + block-scaled e4m3 cross terms (2 product-equivalents on 2/3 of the layer FLOPs)"}
+                      "f16mf": "f16x3; FC1 / FC2 and, from a third of the depth on, the packed projection as f16 + block-scaled e4m3 cross terms"}
         out = {
             "metric": "utterances/sec (10 s @16 kHz) WavLM-large embed extract" if geo is C.WAVLM_LARGE and abs(args.seconds - 10) < 1e-6
                       else f"utterances/sec ({args.seconds:.0f} s @16 kHz) {geo.name} embed extract",
@@ -758,8 +758,9 @@ def main():
                             "v_mfma_scale_f32_16x16x128_f8f6f4 (x_hi w_hi + x_lo w_8 + x_8 w_lo: 2 product-equivalents instead of 3, operand error "
                             "~2^-15); conv stem, attention and output projection on the fp16 hi + lo split (full-depth stress cases: "
                             "profiles/r05_depth_envelope_f16m*.txt, <= 4.8e-4, inside fp32x's on every case)",
-                    "f16mf": "round 5, the drivers' default: f16x with the feed-forward pair (FC1, FC2: 2/3 of the layer FLOPs) in f16m's operand "
-                             "format; packed projection, attention, output projection and conv stem on the fp16 hi + lo split (full-depth stress "
+                    "f16mf": "round 5, the drivers' default: f16x with the feed-forward pair (FC1, FC2: 2/3 of the layer FLOPs) of every layer and "
+                             "the packed projection from a third of the depth on in f16m's operand format; conv stem, attention, output "
+                             "projection and the first third's packed projections on the fp16 hi + lo split (full-depth stress "
                              "cases, all four encoder families: profiles/r05_depth_envelope_f16mf.txt, <= 2.2e-4, 2-7x inside fp32x's on every case)",
                     "f16": "fp32x conv stem (conv stack, projection, positional conv) + fp16 single-product encoder layers",
                     "f16a": "fp32x conv stem; packed QKV projection, attention (S = K Q^T, P V) and output projection on the 3-product "

@@ -51,10 +51,11 @@ def build_parser(whisper: bool) -> argparse.ArgumentParser:
     p.add_argument("--mode", type=str, default="f16mf", choices=["f16mf", "f16x", "f16m", "fp32x", "f16a", "f16q", "f16", "bf16"],
                    help="numerics of the matrix products (errors: max|a-b| / max(1, max|b|) per hidden state against the fp32 reference, all "
                         "states, FULL depth, profiles/r04_depth_envelope*.txt, r05_depth_envelope_f16m*.txt).  f16mf (default since round 5): the "
-                        "3-product split on fp16 hi + lo planes for the conv stem, packed projection, attention and output projection; FC1 / FC2 (2/3 "
-                        "of the layer FLOPs) as fp16 main product + block-scaled e4m3 cross terms on the gfx950 scaled matrix instruction -- 1.4e-5 "
+                        "3-product split on fp16 hi + lo planes for the conv stem, attention, output projection and the first third's packed projections; "
+                        "FC1 / FC2 (2/3 of the layer FLOPs) and the later layers' packed projections as fp16 main product + block-scaled e4m3 cross "
+                        "terms on the gfx950 scaled matrix instruction -- 1.5e-5 "
                         "on Gaussian weights, <= 2.2e-4 under sharp attention / LoRA-scaled queries / outlier channels at 24, 32 and 48 layers in "
-                        "all four encoder families (2-7x inside fp32x's on every case), 1.115x f16x's throughput.  f16x (the default of round 4): "
+                        "all four encoder families (2-7x inside fp32x's on every case), 1.15x f16x's throughput.  f16x (the default of round 4): "
                         "the 3-product split everywhere -- 4e-6 plain, <= 1.5e-4 under the stress cases: the widest margin.  All fp16-plane modes: "
                         "operand values must stay below 65 504 (every kernel that rounds to such a plane reports into a guard "
                         "word read back with every batch, and a batch that saturates FAILS its files).  f16m (round 5): packed projection / FC1 / FC2 "

@@ -31,10 +31,12 @@ from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPE
 
 MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16,
          "f16x": _lib.MODE_FP16X, "f16m": _lib.MODE_FP16M, "f16mf": _lib.MODE_FP16M}
-# "f16mf" (round 5): "f16m" on the FEED-FORWARD pair only -- FC1 and FC2 (2/3 of the layer FLOPs) multiply in SER_MODE_FP16M, the packed
-# projection, ser_attention and the output projection keep "f16x"'s three products on fp16 hi + lo planes.  oracle/numerics_whatif_f16m.py
-# (sites): under sharp attention the error of "f16m" comes from the packed projection (4.3e-4 of its 5.2e-4 at 24 layers); on FC1 + FC2 alone
-# the same operand format gives 1.4e-4 (sharp x2), 2.7e-5 (LoRA), 1.3e-5 (plain) -- inside "fp32x"'s on each.
+# "f16mf" (round 5, the drivers' default): "f16m" where it is benign -- FC1 and FC2 (2/3 of the layer FLOPs) in every layer, the packed
+# projection from a third of the depth on (_EncoderBase.qkv_m_from); the conv stem, ser_attention, the output projection and the first
+# third's packed projections keep "f16x"'s three products on fp16 hi + lo planes.  oracle/numerics_whatif_f16m.py (site lists): under sharp
+# attention the error of "f16m" comes from the packed projections of the FIRST layers (an error injected by layer i passes through L - i
+# more softmax layers): all of them 4.3e-4 of f16m's 5.2e-4 at 24 layers, from layer 8 on nothing measurable; FC1 + FC2 alone give 1.4e-4
+# (sharp x2), 2.7e-5 (LoRA), 1.3e-5 (plain) -- inside "fp32x"'s on each.  The stem in that format: 1.4e-3 (it stays on 22 bits).
 # "f16m" (round 5): the encoder layers' GEMMs on SER_MODE_FP16M operands -- fp16 main product + block-scaled e4m3 cross terms on gfx950's
 # v_mfma_scale_f32_16x16x128_f8f6f4: 2 product-equivalents per algorithmic FLOP instead of "f16x"'s 3 (include/ser_hip.h).  The packed
 # projection, FC1 and FC2 multiply in it; ser_attention and the output projection (8 % of the layer FLOPs, its A operand is the attention
@@ -254,12 +256,20 @@ class _EncoderBase:
             self.stem_mode = _lib.MODE_FP16X
         # WavLM gate inside ser_attention (see the note at the top).  "f16m": as 2H columns of the packed projection instead -- the in-kernel form
         # multiplies the layer input's operand copy, whose second plane is e4m3 bytes in that mode
-        self.gate_in_attn = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1" and mode != "f16m"
+        self.gate_in_attn = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1"
         self.qk_mode = _lib.MODE_FP16X if mode == "f16q" else None             # logit path on its own launch (None: one packed launch)
         self.attn_mode = _lib.MODE_FP16X if mode in ("f16a", "f16m", "f16mf") else self.mode   # attention kernel, context rows, output projection
-        self.qkv_mode = _lib.MODE_FP16M if mode == "f16m" else self.attn_mode  # packed projection
+        self.qkv_mode = self.attn_mode                                         # packed projection (layers before qkv_m_from)
         self.x_mode = self.qk_mode or self.qkv_mode                            # format of the operand copy the packed projection reads
-        self.qkv_out_mode = self.attn_mode if mode == "f16m" else self.x_mode  # format of q, k, v (what ser_attention reads)
+        self.qkv_out_mode = self.x_mode                                        # format of q, k, v (what ser_attention reads)
+        # First layer whose PACKED PROJECTION multiplies in SER_MODE_FP16M (see _lay_modes): "f16m" 0 = every layer; "f16mf" a third of the
+        # depth (8 of 24, 16 of 48, 11 of 32).  An operand error injected by layer i passes through L - i more softmax layers: the what-if
+        # (oracle/numerics_whatif_f16m.py, sites "qkv>=N") puts the packed projection in that format from layer 8 of 24 on at 1.44e-4 / 3.7e-5
+        # (sharp x2 / LoRA) against 1.43e-4 / 2.7e-5 with none and 5.2e-4 / 4.7e-4 with all -- its error lives in the first layers.
+        self.qkv_m_from: Optional[int] = {"f16m": 0, "f16mf": (geo.num_layers + 2) // 3}.get(mode)
+        if mode == "f16mf" and _os.environ.get("SER_F16MF_QKV_FROM"):          # A/B knob (tools/): -1 = never
+            v = int(_os.environ["SER_F16MF_QKV_FROM"])
+            self.qkv_m_from = None if v < 0 else v
         self.planes, self.stem_planes = _PLANES[self.mode], _PLANES[self.stem_mode]
         self._cache: Dict = {}
         # when a list, every ser_gemm launch appends (start_event, end_event, algorithmic_flops):
@@ -284,6 +294,15 @@ class _EncoderBase:
             t = pl["range_flag"] = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._flag = t.data_ptr()
         return t
+
+    def _lay_modes(self, i: int) -> dict:
+        """Formats around layer i's packed projection: the GEMM's mode, the layer input's operand copy it reads (written by ser_row_center for
+        layer 0, by FC2 of layer i - 1 otherwise), q / k / v as ser_attention reads them, and where the WavLM gate is evaluated.  With the
+        projection in SER_MODE_FP16M the gate rides as 2H extra output columns: the in-kernel form multiplies the layer input's operand copy,
+        whose second plane is e4m3 bytes in that format."""
+        if self.qkv_m_from is not None and i >= self.qkv_m_from:
+            return dict(qkv_mode=_lib.MODE_FP16M, x_mode=_lib.MODE_FP16M, qkv_out_mode=self.attn_mode, gate_in_attn=False)
+        return dict(qkv_mode=self.qkv_mode, x_mode=self.x_mode, qkv_out_mode=self.qkv_out_mode, gate_in_attn=self.gate_in_attn)
 
     def _check_last_state(self, last_state: Optional[int]) -> Optional[int]:
         if last_state is None:
@@ -453,7 +472,7 @@ class _EncoderBase:
         if rec is not None:
             a = rec.slot("row_center")
             a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride = x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride
-            a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.x_mode, rows, D
+            a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self._lay_modes(0)["x_mode"], rows, D
             if out_act.scale is not None:
                 a.out_scale, a.out_scale_ld = out_act.scale.data_ptr(), out_act.scale_ld
             a.range_flag = self._flag
@@ -461,7 +480,7 @@ class _EncoderBase:
             return
         a = _lib.RowCenterArgs()
         a.x, a.ldx, a.out_act, a.ldo_act, a.out_plane_stride = x.data_ptr(), D, out_act.ptr, out_act.cols, out_act.plane_stride
-        a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self.x_mode, rows, D
+        a.stats, a.shift, a.stat_groups, a.mode, a.rows, a.D = stats.data_ptr(), shift.data_ptr(), groups, self._lay_modes(0)["x_mode"], rows, D
         if out_act.scale is not None:
             a.out_scale, a.out_scale_ld = out_act.scale.data_ptr(), out_act.scale_ld
         a.range_flag = self._flag
@@ -501,7 +520,8 @@ class _EncoderBase:
 
     def _gate_pad(self) -> int:
         """extra columns of the packed projection: the WavLM gate's two pre-activations per head, padded to a multiple of 8"""
-        return ((2 * self.geo.heads + 7) // 8) * 8 if (self.geo.family == FAMILY_WAVLM and not self.gate_in_attn) else 0
+        in_cols = any(not self._lay_modes(i)["gate_in_attn"] for i in range(self.geo.num_layers))   # some layer keeps the gate in the projection
+        return ((2 * self.geo.heads + 7) // 8) * 8 if (self.geo.family == FAMILY_WAVLM and in_cols) else 0
 
     def _qkv_cols(self):
         """(q, k, v, gate) first columns inside the packed projection output"""
@@ -521,7 +541,7 @@ class _EncoderBase:
         lnstat = pl["gst"] if "gate_w" in lay else None     # (relative mean, rstd) per row for the attention kernel's in-kernel gate
         if self.qk_mode is None:
             self._gemm(pl["xa"], lay["qkv"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
-                       col_scale_end=D, ln_mean=ln_mean, mode=self.qkv_mode, out_mode=self.qkv_out_mode, lnstat_out=lnstat)
+                       col_scale_end=D, ln_mean=ln_mean, mode=lay["qkv_mode"], out_mode=lay["qkv_out_mode"], lnstat_out=lnstat)
             return
         self._gemm(pl["xa"], lay["qk"], M, ln_stats=stats, ln_groups=gx, out_act=pl["qkv"], col_scale=scale,
                    col_scale_end=D, ln_mean=ln_mean, mode=self.qk_mode, lnstat_out=lnstat)
@@ -582,7 +602,7 @@ class _EncoderBase:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D)
             else:
                 self._gemm(pl["ffn"], lay["fc2"], M, residual=pl["h"], ldr=D, out_f32=nxt, ldo_f32=D,
-                           out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD, out_mode=self.x_mode,
+                           out_act=pl["xa"], stat_out=pl["px"], stat_groups=gD, out_mode=self.layers[i + 1]["x_mode"],
                            shift=(pl["mh"], pl["sx"], lay["fc2_bias_mean"]) if shifted else None)
             gx = gD
             if not last:
@@ -624,15 +644,16 @@ class _EncoderBase:
                        mode=self.attn_mode, out_mode=self.mode)
         return len(self.layers)
 
-    def _layer_weights(self, sd, p: str, a: str, ln1: str, ln2: str, fc1: str, fc2: str, k_bias: bool, gate: bool):
+    def _layer_weights(self, sd, p: str, a: str, ln1: str, ln2: str, fc1: str, fc2: str, k_bias: bool, gate: bool, index: int = 0):
         """One encoder layer's GEMM operands; LN1 folds into the packed QKV (+gate) projection, LN2 into FC1."""
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
+        lm = self._lay_modes(index)
         wdev = sd[a + ".q_proj.weight"].device            # CPU state dict, or device views of the broadcast bucket (dist.py)
         kb = sd[a + ".k_proj.bias"] if k_bias else torch.zeros(D, device=wdev)
         ws = [sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]]
         bs = [sd[a + ".q_proj.bias"], kb, sd[a + ".v_proj.bias"]]
-        lay = {}
-        if gate and self.gate_in_attn:
+        lay = dict(qkv_mode=lm["qkv_mode"], x_mode=lm["x_mode"], qkv_out_mode=lm["qkv_out_mode"])
+        if gate and lm["gate_in_attn"]:
             # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in LN1(x) restricted to the
             # head's dh channels.  ser_attention evaluates them per query from the layer input's operand copy with the LayerNorm in
             # closed form (ser_attention_args.gate_x): pre_j = rstd (x . (gamma w_j) - mean sum(gamma w_j)) + (beta . w_j + b_j)
@@ -660,7 +681,7 @@ class _EncoderBase:
             bs.append(torch.cat([torch.stack([b8[:4].sum(), b8[4:].sum()]).repeat(H), torch.zeros(pad, device=wdev)]))
             lay["gate_c"] = self._dev_f32(sd[a + ".gru_rel_pos_const"].reshape(-1))
         if self.qk_mode is None:
-            lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=self.qkv_mode)
+            lay["qkv"] = self._linear_ln(torch.cat(ws, 0), torch.cat(bs, 0), sd[ln1 + ".weight"], sd[ln1 + ".bias"], mode=lm["qkv_mode"])
         else:
             # logit path [q | k | gate] on fp16 hi + lo planes (3 products), [v] on one fp16 plane
             lay["qk"] = self._linear_ln(torch.cat(ws[:2] + ws[3:], 0), torch.cat(bs[:2] + bs[3:], 0), sd[ln1 + ".weight"],
@@ -679,7 +700,9 @@ class _EncoderBase:
         D, Fd = geo.hidden, geo.ffn
         nqkv = 3 * D + self._gate_pad()
         gD = self._stat_groups(D)
-        pl["xa"] = self._new_act(M, D, mode=self.x_mode)
+        # (an FP16M buffer serves FP16X layers too: same two fp16-sized planes, the block-scale words are simply not touched)
+        x_modes = {self._lay_modes(i)["x_mode"] for i in range(geo.num_layers)}
+        pl["xa"] = self._new_act(M, D, mode=_lib.MODE_FP16M if _lib.MODE_FP16M in x_modes else self.x_mode)
         pl["ha"] = self._new_act(M, D)
         if self.fp16_planes:
             pl["range_flag"] = torch.zeros(1, dtype=torch.int32, device=dev)   # the slot's fp16 range-guard word (HiddenStates.range_flag)
@@ -693,7 +716,7 @@ class _EncoderBase:
         pl["gst"] = torch.zeros((M, 2), dtype=torch.float32, device=dev)  # (relative mean, rstd) of x's rows (packed projection -> attention's gate)
         pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
         pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
-        pl["qkv"] = self._new_act(M, nqkv, mode=self.qkv_out_mode)   # "f16q": q, k, gate columns carry a lo plane, v's stays unused
+        pl["qkv"] = self._new_act(M, nqkv, mode=self._lay_modes(geo.num_layers - 1)["qkv_out_mode"])   # "f16q": q, k, gate columns carry a lo plane, v's stays unused
         pl["ctx"] = self._new_act(M, D, mode=self.attn_mode)
         pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         pl["ffn"] = self._new_act(M, Fd)
@@ -817,7 +840,7 @@ class SpeechEncoder(_EncoderBase):
             self.layers.append(self._layer_weights(
                 sd, p, p + ".attention", p + ".layer_norm", p + ".final_layer_norm",
                 p + ".feed_forward.intermediate_dense", p + ".feed_forward.output_dense",
-                k_bias=True, gate=(geo.family == FAMILY_WAVLM)))
+                k_bias=True, gate=(geo.family == FAMILY_WAVLM), index=i))
         if geo.family == FAMILY_WAVLM:
             self.rel_embed = self._dev_f32(sd["encoder.layers.0.attention.rel_attn_embed.weight"])
 
@@ -1099,7 +1122,7 @@ class WhisperEncoder(_EncoderBase):
             p = f"encoder.layers.{i}"
             self.layers.append(self._layer_weights(
                 sd, p, p + ".self_attn", p + ".self_attn_layer_norm", p + ".final_layer_norm",
-                p + ".fc1", p + ".fc2", k_bias=False, gate=False))        # k_proj has no bias
+                p + ".fc1", p + ".fc2", k_bias=False, gate=False, index=i))        # k_proj has no bias
 
     def _plan(self, lengths, slot: int = 0):
         """Every Whisper shape is a function of B alone (30 s windows), so buffers are keyed by (slot, B) and a new

@@ -81,7 +81,18 @@ def mm(x, W, arith):
 def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
     """sites: which GEMMs run `arith`; the others and the attention core run fp16 hi + lo planes ('f16x')."""
     # site names: "qkv" (= "q", "k", "v" together), "out", "fc1", "fc2"; "pv1": P and V of the context product on ONE fp16 plane each
-    A = lambda site: arith if (site in sites or (site in ("q", "k", "v") and "qkv" in sites)) else "f16x"    # noqa: E731
+    # a site may carry a first layer, "qkv>=12": the arithmetic from that layer on (errors injected late pass through fewer softmax layers)
+    first = {}
+    for e in sites:
+        name, _, n = e.partition(">=")
+        first[name] = int(n) if n else 0
+    layer_now = [0]
+
+    def A(site):
+        for name in (site, "qkv" if site in ("q", "k", "v") else site):
+            if name in first and layer_now[0] >= first[name]:
+                return arith
+        return "f16x"
     eps, H, dh, D = geo.layer_norm_eps, geo.heads, geo.head_dim, geo.hidden
     sd = {k: v.double() for k, v in sd.items()}
     h = h0.double()
@@ -97,6 +108,7 @@ def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
         return mm(x - mu, W * g[None, :], A(site)) * torch.rsqrt(var + eps) + (W @ be + (b if b is not None else 0.0))
 
     for i in range(geo.num_layers):
+        layer_now[0] = i
         states.append(h)
         p = f"encoder.layers.{i}"
         a = p + ".attention"
@@ -112,7 +124,7 @@ def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
         q = deferred_ln_linear(h, p + ".layer_norm", Wq, bq, "q") * dh ** -0.5
         k = deferred_ln_linear(h, p + ".layer_norm", Wk, bk, "k")
         v = deferred_ln_linear(h, p + ".layer_norm", Wv, bv, "v")
-        pv1 = "pv1" in sites and arith != "exact"
+        pv1 = "pv1" in first and i >= first["pv1"] and arith != "exact"
         qh, kh = (O._heads(core(t), H) for t in (q, k))
         vh = O._heads(r16(v) if pv1 else core(v), H)
         scores = qh @ kh.transpose(1, 2)
