@@ -13,8 +13,8 @@ and a ragged 3 s + 10 s pair against oracle.ssl_oracle.speech_hidden_states):
   * "fp32x" (bf16 hi + lo): <= 8e-4 (sharp x2 7.9e-4 / 4.8e-4, LoRA 7.4e-4 / 6.9e-4): inside the gate, little margin;
   * "f16a" (round 3's default: single-product fp16 feed-forward): 3.7e-3 / 2.9e-3 under sharp attention -- the feed-forward's rounding,
     benign in 2-3 layers, is amplified by 24-48: it LEAVES the gate, which is why it is no longer the default; <= 6e-4 elsewhere;
-  * "f16mf" (round 5: f16m's operand format on the feed-forward pair only -- the packed projection, where sharp attention amplifies operand
-    rounding, keeps f16x's 22 bits; 1.115 x f16x's throughput): WavLM-large 1.4e-5 plain, 1.75e-4 sharp x2, 9.1e-5 LoRA, 4.9e-6 outliers;
+  * "f16mf" (round 5, the drivers' default: f16m's operand format on the feed-forward pair of every layer and on the packed projection from a
+    third of the depth on -- the early packed projections, whose rounding every later softmax amplifies, keep f16x's 22 bits; 1.15 x f16x's throughput): WavLM-large 1.4e-5 plain, 1.75e-4 sharp x2, 9.1e-5 LoRA, 4.9e-6 outliers;
     HuBERT-xlarge sharp x2 1.2e-4; Whisper-large-v3 sharp x2 1.7e-4 -- inside fp32x's on EVERY case by 2-7 x and inside the default's 4x margin.
   * "f16m" (round 5: packed projection / FC1 / FC2 as fp16 main product + block-scaled e4m3 cross terms, ~2^-15 operands, 1.1 x f16x's
     throughput; profiles/r05_depth_envelope_f16m*.txt): WavLM-large 1.7e-5 plain, 4.8e-4 sharp x2, 4.2e-4 LoRA, 6e-6 outliers -- inside
