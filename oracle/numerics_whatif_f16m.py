@@ -15,6 +15,9 @@ A fifth argument lists variants as arith@site+site...: sites q, k, v (qkv = all 
 "pv1" puts P and V of the context product on ONE fp16 plane each.  Round 5, WavLM-large, 5 s, worst state (sharp x2 / LoRA): f16m8 everywhere
 5.2e-4 / 4.7e-4; @qkv 4.3e-4 / 4.4e-4; @fc1+fc2 1.4e-4 / 2.7e-5 (= the "f16mf" mode, the drivers' default); @fc1+fc2+out 1.9e-4 / 1.7e-4;
 @fc1+fc2+v 1.8e-4 / 1.5e-4; @fc1+fc2+q 3.2e-4 / 3.0e-4; @fc1+fc2+k 3.5e-4 / 3.4e-4; @fc1+fc2+pv1 3.5e-3 / 3.5e-3; f16x 2.1e-5 / 1.6e-5; bf16x3 1.9e-4 / 2.4e-4.
+Sites may carry a first layer (qkv>=8) and groups may be chained (f16m8@fc1+fc2+qkv>=8;f16@fc1>=22+fc2>=22): qkv>=8 1.44e-4 / 3.7e-5, qkv>=6
+1.67e-4 / 3.6e-5, qkv>=4 1.75e-4 / 4.4e-5, qkv>=2 2.4e-4 / 1.2e-4, qkv>=8+out>=8 1.44e-4 / 4.1e-5; single fp16 products in the feed-forward of the
+last 2 / 4 layers on top of qkv>=8: 1.6e-4 / 4.1e-5 and 1.9e-4 / 3.8e-5.
 `... stem [model] [seconds]`: the conv stem's layers 1-6 in each format behind exact layers -- last hidden state under sharp x2 (3 s): f16x 6.6e-5,
 bf16x3 6.2e-4, f16m8 1.4e-3 (outside the gate: every stem error passes through all 24 softmax layers -- the stem stays on 22-bit operands).
 Error form of the tests: max|a - b| / max(1, max|b|) per hidden state, worst state, against the all-exact fp64 run.
@@ -82,16 +85,25 @@ def layers(geo, sd, h0, arith, sites=("qkv", "out", "fc1", "fc2")):
     """sites: which GEMMs run `arith`; the others and the attention core run fp16 hi + lo planes ('f16x')."""
     # site names: "qkv" (= "q", "k", "v" together), "out", "fc1", "fc2"; "pv1": P and V of the context product on ONE fp16 plane each
     # a site may carry a first layer, "qkv>=12": the arithmetic from that layer on (errors injected late pass through fewer softmax layers)
-    first = {}
-    for e in sites:
-        name, _, n = e.partition(">=")
-        first[name] = int(n) if n else 0
+    # `arith` may also be a list of (arithmetic, sites) groups -- "f16m8@fc1+fc2+qkv>=8;f16@fc1>=20+fc2>=20": the LAST group that names a
+    # site at the current layer wins
+    groups = arith if isinstance(arith, list) else [(arith, sites)]
+    arith = groups[0][0]
+    parsed = []
+    for ar, ss in groups:
+        f = {}
+        for e in ss:
+            name, _, n = e.partition(">=")
+            f[name] = int(n) if n else 0
+        parsed.append((ar, f))
+    first = parsed[0][1]
     layer_now = [0]
 
     def A(site):
-        for name in (site, "qkv" if site in ("q", "k", "v") else site):
-            if name in first and layer_now[0] >= first[name]:
-                return arith
+        for ar, f in reversed(parsed):
+            for name in (site, "qkv" if site in ("q", "k", "v") else site):
+                if name in f and layer_now[0] >= f[name]:
+                    return ar
         return "f16x"
     eps, H, dh, D = geo.layer_norm_eps, geo.heads, geo.head_dim, geo.hidden
     sd = {k: v.double() for k, v in sd.items()}
@@ -214,12 +226,17 @@ def main():
         variants = [("f16x", None), ("bf16x3", None), ("f16m8", None), ("f16m6", None), ("f16", ("fc1", "fc2")), ("f16", None)]
         if len(sys.argv) > 4:
             # "f16m8@fc1+fc2": the arithmetic on those GEMMs only, fp16 hi + lo planes (f16x) on the others
-            variants = [(v.split("@")[0], tuple(v.split("@")[1].split("+")) if "@" in v else None) for v in sys.argv[4].split(",")]
+            variants = []
+            for v in sys.argv[4].split(","):
+                if ";" in v:
+                    variants.append(([(g.split("@")[0], tuple(g.split("@")[1].split("+"))) for g in v.split(";")], "groups"))
+                else:
+                    variants.append((v.split("@")[0], tuple(v.split("@")[1].split("+")) if "@" in v else None))
         for arith, sites in variants:
             got = layers(geo, ref_sd, h0, arith) if sites is None else layers(geo, ref_sd, h0, arith, sites)
             per = [float((a - b).abs().max() / max(1.0, float(b.abs().max()))) for a, b in zip(got, exact)]
             L = len(per) - 1
-            tag = arith + ("" if sites is None else " on " + "+".join(sites))
+            tag = (";".join(a + "@" + "+".join(ss) for a, ss in arith) if isinstance(arith, list) else arith + ("" if sites is None else " on " + "+".join(sites)))
             print(f"  {tag:22s} state {L // 2}: {per[L // 2]:.2e}   state {L}: {per[L]:.2e}   worst {max(per):.2e}")
             sys.stdout.flush()
 
