@@ -166,6 +166,32 @@ def test_sharp_attention_fixtures(golden_dir, case):
     assert worst["f16"] < 3e-2 and worst["bf16"] < 5e-1, worst            # sanity only: these modes do not claim this regime
 
 
+def test_default_mode_layer_formats():
+    """The drivers' default ("f16mf"): FC1 / FC2 of every layer in SER_MODE_FP16M, the packed projection from a third of the depth on
+    (engine._lay_modes; oracle/numerics_whatif_f16m.py "qkv>=N"), FP16X before that with the WavLM gate inside ser_attention; "f16m" takes
+    the cheap format from layer 0, "f16x" never; and FC2 writes the next layer's operand copy in the format that layer reads."""
+    from interspeech_ser_amd import _lib
+    from interspeech_ser_amd import config as C
+    from interspeech_ser_amd.engine import SpeechEncoder
+    from interspeech_ser_amd.weights import synthetic_state_dict
+    geo = C.TINY_WAVLM
+    sd = synthetic_state_dict(geo, 3)
+    L = geo.num_layers
+    want = {"f16mf": (L + 2) // 3, "f16m": 0, "f16x": None}
+    assert [(n + 2) // 3 for n in (24, 48, 32)] == [8, 16, 11]
+    for mode, first in want.items():
+        enc = SpeechEncoder(geo, sd, "cuda:0", mode=mode)
+        assert enc.qkv_m_from == first
+        for i, lay in enumerate(enc.layers):
+            m = first is not None and i >= first
+            assert lay["qkv_mode"] == (_lib.MODE_FP16M if m else _lib.MODE_FP16X), (mode, i)
+            assert lay["x_mode"] == lay["qkv_mode"] and lay["qkv_out_mode"] == _lib.MODE_FP16X
+            assert ("gate_w" in lay) == (not m), (mode, i)                 # in-kernel gate on the hi + lo copy; gate columns beside FP16M projections
+            assert lay["fc1"].wscale is not None if mode != "f16x" else lay["fc1"].wscale is None
+        del enc
+    torch.cuda.empty_cache()
+
+
 def test_batched_equals_single(golden_dir):
     """Packed ragged batch == batch-of-one runs (the reference's B=1 loop), to fp32 rounding."""
     from interspeech_ser_amd import config as C
