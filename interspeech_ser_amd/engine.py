@@ -254,8 +254,8 @@ class _EncoderBase:
         self.stem_mode = (_lib.MODE_FP16X if _STEM_F16X else _lib.MODE_FP32X) if mode in ("f16", "f16q", "f16a") else self.mode
         if mode in ("f16m", "f16mf"):
             self.stem_mode = _lib.MODE_FP16X
-        # WavLM gate inside ser_attention (see the note at the top).  "f16m": as 2H columns of the packed projection instead -- the in-kernel form
-        # multiplies the layer input's operand copy, whose second plane is e4m3 bytes in that mode
+        # WavLM gate inside ser_attention (see the note at the top) -- except beside a packed projection in SER_MODE_FP16M, where it rides as 2H
+        # extra output columns (per layer: _lay_modes)
         self.gate_in_attn = _os.environ.get("SER_GATE_IN_ATTN", "1") == "1"
         self.qk_mode = _lib.MODE_FP16X if mode == "f16q" else None             # logit path on its own launch (None: one packed launch)
         self.attn_mode = _lib.MODE_FP16X if mode in ("f16a", "f16m", "f16mf") else self.mode   # attention kernel, context rows, output projection
