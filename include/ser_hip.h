@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SER_ABI_VERSION 13
+#define SER_ABI_VERSION 14
 
 #define SER_MODE_BF16  1   /* act tensors have 1 plane; GEMMs do 1 bf16 MFMA product   */
 #define SER_MODE_FP32X 2   /* act tensors have 2 planes; GEMMs do hi*hi + lo*hi + hi*lo */
@@ -332,7 +332,7 @@ typedef struct ser_attention_args {
     const int32_t* frame_offs; const float* table; const float* gate;
     int32_t max_frames, table_T;
     void* out; int64_t ldo; int64_t out_plane_stride;
-    int32_t H, dh; float scale; int32_t mode; int32_t gate_col, reserved0;
+    int32_t H, dh; float scale; int32_t mode; int32_t gate_col, out_mode;   /* out_mode: 0 = `mode`'s planes, SER_MODE_FP16M: see out_scale */
     const float* gru_const; const int32_t* key_lens;
     const float* bias2d; int64_t bias2d_ld;
     /* WavLM gate computed INSIDE the kernel (round 3; ser_attention_v only): the two pre-activations per (row, head) are linear in
@@ -348,6 +348,10 @@ typedef struct ser_attention_args {
     const float* gate_stat; const void* gate_w; const float* gate_cb;
     int32_t gate_x_planes, reserved1;
     int64_t gate_w_plane_stride;
+    /* ABI 14: context rows as SER_MODE_FP16M operands for an output projection in that format (out_mode = SER_MODE_FP16M; mode FP16X,
+     * head dim 64 -- a head is one 64-column tile): plane 0 of `out` = the fp16 copy, plane 1 = [P | Q] e4m3 bytes, out_scale[D / 64][out_scale_ld]
+     * = one word of four E8M0 codes per (head, row).  The reference has no counterpart (fp32 end to end, preprocess_speech.py:50). */
+    uint32_t* out_scale; int64_t out_scale_ld;
 } ser_attention_args;
 /* ser_attention with its arguments in a struct (the form command lists carry); the only entry point that takes the gate_x fields. */
 int ser_attention_v(const ser_attention_args* args, void* stream);

@@ -25,7 +25,7 @@ ACT_NONE = 0
 ACT_GELU = 1
 WS_LOGMEL = 1
 WS_WAVE_FRAMES = 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -63,12 +63,13 @@ class AttentionArgs(C.Structure):
         ("max_frames", C.c_int32), ("table_T", C.c_int32),
         ("out", c_void_p), ("ldo", c_i64), ("out_plane_stride", c_i64),
         ("H", C.c_int32), ("dh", C.c_int32), ("scale", c_float), ("mode", C.c_int32),
-        ("gate_col", C.c_int32), ("reserved0", C.c_int32),
+        ("gate_col", C.c_int32), ("out_mode", C.c_int32),
         ("gru_const", c_void_p), ("key_lens", c_void_p),
         ("bias2d", c_void_p), ("bias2d_ld", c_i64),
         ("gate_x", c_void_p), ("gate_x_ld", c_i64), ("gate_x_plane_stride", c_i64),
         ("gate_stat", c_void_p), ("gate_w", c_void_p), ("gate_cb", c_void_p),
         ("gate_x_planes", C.c_int32), ("reserved1", C.c_int32), ("gate_w_plane_stride", c_i64),
+        ("out_scale", c_void_p), ("out_scale_ld", c_i64),
     ]
 
 

@@ -609,6 +609,60 @@ void attention_kernel(const AttnParams p) {
                                p.dbg[(wave * 64 + 62) * 6 + 2] = __builtin_amdgcn_s_memrealtime() - dbg_entry_rt; }
 #endif
     // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane owns query q, 4 consecutive d per register quad
+    // Context rows as SER_MODE_FP16M operands (round 5, head dim 64: a head is one 64-column tile of the output projection's A operand):
+    // plane 0 = the fp16 copy, plane 1 = per row and head 128 bytes [P = v - hi: 64 e4m3 | Q = v: 64 e4m3] with one E8M0 scale per 32
+    // columns, packed as the word out_scale[head][row] = [P 0-31, P 32-63, Q 0-31, Q 32-63] (include/ser_hip.h SER_MODE_FP16M).  A query's 32
+    // columns of a block sit in lanes l and l ^ 32 (16 each): one cross-lane max per block and plane.  Every lane takes part in the shuffles.
+    if constexpr (MODE == SER_MODE_FP16X && DHP == 64) {
+        if (p.out_scale) {
+            const float inv = (q < T) ? 1.0f / l_run : 0.f;
+            const int64_t row = (int64_t)row0 + (q < T ? q : 0);
+            unsigned short* orow = p.out + row * p.ldo + h * dh;
+            unsigned char* seg = (unsigned char*)(p.out + p.out_plane) + (row * p.ldo + h * dh) * 2;
+            unsigned codes = 0;
+#pragma unroll
+            for (int ds = 0; ds < DSUB; ++ds) {
+                float v[16], lo[16], ax = 0.f, al = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    v[i] = ot[ds][i] * inv; v[i + 1] = ot[ds][i + 1] * inv;
+                    const unsigned h2 = pack_h2(v[i], v[i + 1]);
+                    lo[i] = v[i] - h2f((unsigned short)(h2 & 0xffffu));
+                    lo[i + 1] = v[i + 1] - h2f((unsigned short)(h2 >> 16));
+                    ax = fmaxf(ax, fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
+                    al = fmaxf(al, fmaxf(fabsf(lo[i]), fabsf(lo[i + 1])));
+                }
+                ax = fmaxf(ax, __shfl_xor(ax, 32, 64));
+                al = fmaxf(al, __shfl_xor(al, 32, 64));
+                const unsigned cx = mx_code(ax), cl = mx_code(al);
+                const float ix = mx_inv(cx), il = mx_inv(cl);
+                codes |= (cl << (8 * ds)) | (cx << (16 + 8 * ds));
+                // lanes l (hh = 0) and l + 32 (hh = 1) hold the interleaved 4-column groups of the block: v_permlane32_swap trades two of each
+                // lane's four groups so that hh = 0 ends up with columns 0-15 and hh = 1 with 16-31 -- 16-byte stores (2 per plane and block)
+                unsigned ha[4], hb[4], pw[4], qw[4];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    ha[r4] = pack_h2(v[4 * r4], v[4 * r4 + 1]);
+                    hb[r4] = pack_h2(v[4 * r4 + 2], v[4 * r4 + 3]);
+                    pw[r4] = mx_pack4(lo[4 * r4] * il, lo[4 * r4 + 1] * il, lo[4 * r4 + 2] * il, lo[4 * r4 + 3] * il);
+                    qw[r4] = mx_pack4(v[4 * r4] * ix, v[4 * r4 + 1] * ix, v[4 * r4 + 2] * ix, v[4 * r4 + 3] * ix);
+                }
+                const auto a0 = __builtin_amdgcn_permlane32_swap(ha[0], ha[2], false, false), b0 = __builtin_amdgcn_permlane32_swap(hb[0], hb[2], false, false);
+                const auto a1 = __builtin_amdgcn_permlane32_swap(ha[1], ha[3], false, false), b1 = __builtin_amdgcn_permlane32_swap(hb[1], hb[3], false, false);
+                const auto p0 = __builtin_amdgcn_permlane32_swap(pw[0], pw[2], false, false), p1 = __builtin_amdgcn_permlane32_swap(pw[1], pw[3], false, false);
+                const auto q0_ = __builtin_amdgcn_permlane32_swap(qw[0], qw[2], false, false), q1_ = __builtin_amdgcn_permlane32_swap(qw[1], qw[3], false, false);
+                if (q < T) {
+                    const int c0 = ds * 32 + 16 * hh;                     // this lane's 16 columns of the block
+                    *(u32x4*)(orow + c0) = (u32x4){a0[0], b0[0], a0[1], b0[1]};
+                    *(u32x4*)(orow + c0 + 8) = (u32x4){a1[0], b1[0], a1[1], b1[1]};
+                    *(u32x4*)(seg + c0) = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+                    *(u32x4*)(seg + 64 + c0) = (u32x4){q0_[0], q0_[1], q1_[0], q1_[1]};
+                }
+            }
+            if (q < T && hh == 0) p.out_scale[(int64_t)h * p.out_scale_ld + row] = codes;
+            return;
+        }
+    }
     if (q < T) {
         const float inv = 1.0f / l_run;
         unsigned short* orow = p.out + (int64_t)(row0 + q) * p.ldo + h * dh;
@@ -667,6 +721,10 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
         if ((args->gate_x_ld % 8) || (args->gate_x_plane_stride % 8) || (args->gate_w_plane_stride % 8) || args->gate_x_planes != np_ || (args->dh % 8))
             return ser_fail(-13, "ser_attention: gate_x / gate_w pitch, or gate_x_planes != the planes of mode %d", args->mode);
     }
+    if (args->out_mode && args->out_mode != SER_MODE_FP16M) return ser_fail(-14, "ser_attention: out_mode %d (0 or SER_MODE_FP16M)", args->out_mode);
+    if (args->out_mode == SER_MODE_FP16M &&
+        (args->mode != SER_MODE_FP16X || args->dh != 64 || !args->out_scale || (args->ldo % 64) || args->bias2d || args->out_scale_ld <= 0))
+        return ser_fail(-14, "ser_attention: SER_MODE_FP16M context rows need mode FP16X, head dim 64, out_scale, ldo %% 64 == 0 and no bias2d");
     if (B <= 0 || H <= 0 || max_frames <= 0) return ser_fail(-2, "ser_attention: bad B/H/max_frames");
     if (dh % 8 || dh < 8 || dh > 128) return ser_fail(-3, "ser_attention: head dim %d unsupported (multiple of 8, <= 128)", dh);
     if ((ld % 8) || (ldo % 4) || (q_col % 8) || (k_col % 8) || (v_col % 8)) return ser_fail(-4, "ser_attention: misaligned pitches/columns");
@@ -732,6 +790,7 @@ extern "C" int ser_attention_v(const ser_attention_args* args, void* stream) {
     p.out = (unsigned short*)out; p.ldo = ldo; p.out_plane = out_plane_stride;
     p.H = H; p.dh = dh; p.bias_stride = bias_stride; p.scale = scale;
     p.bias2d = bias2d; p.b2d_ld = bias2d_ld; p.b2d_T = max_frames;
+    p.out_scale = args->out_mode == SER_MODE_FP16M ? (unsigned*)args->out_scale : nullptr; p.out_scale_ld = args->out_scale_ld;
 #ifdef SER_ATTN_DBG
     p.dbg = (unsigned long long*)ser_attn_dbg_ptr;
 #endif

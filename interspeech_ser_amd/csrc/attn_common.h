@@ -37,6 +37,9 @@ struct AttnParams {
     const float* bias2d;
     int64_t b2d_ld;
     int b2d_T;            // rows per (utterance, head) block of bias2d (= max_frames: uniform-length batches)
+    // context rows as SER_MODE_FP16M operands (ser_attention_args.out_mode): block-scale words [D / 64][out_scale_ld], or null
+    unsigned* out_scale;
+    int64_t out_scale_ld;
 #ifdef SER_ATTN_DBG
     unsigned long long* dbg;   // phase timestamps of one wave (tools/attn_phases.py; never in the product build)
 #endif

@@ -32,15 +32,15 @@ from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPE
 MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16,
          "f16x": _lib.MODE_FP16X, "f16m": _lib.MODE_FP16M, "f16mf": _lib.MODE_FP16M}
 # "f16mf" (round 5, the drivers' default): "f16m" where it is benign -- FC1 and FC2 (2/3 of the layer FLOPs) in every layer, the packed
-# projection from a third of the depth on (_EncoderBase.qkv_m_from); the conv stem, ser_attention, the output projection and the first
-# third's packed projections keep "f16x"'s three products on fp16 hi + lo planes.  oracle/numerics_whatif_f16m.py (site lists): under sharp
+# projection and (head dim 64) the output projection from a third of the depth on (_EncoderBase.qkv_m_from, _lay_modes); the conv stem,
+# ser_attention and the first third's projections keep "f16x"'s three products on fp16 hi + lo planes.  oracle/numerics_whatif_f16m.py (site lists): under sharp
 # attention the error of "f16m" comes from the packed projections of the FIRST layers (an error injected by layer i passes through L - i
 # more softmax layers): all of them 4.3e-4 of f16m's 5.2e-4 at 24 layers, from layer 8 on nothing measurable; FC1 + FC2 alone give 1.4e-4
 # (sharp x2), 2.7e-5 (LoRA), 1.3e-5 (plain) -- inside "fp32x"'s on each.  The stem in that format: 1.4e-3 (it stays on 22 bits).
 # "f16m" (round 5): the encoder layers' GEMMs on SER_MODE_FP16M operands -- fp16 main product + block-scaled e4m3 cross terms on gfx950's
 # v_mfma_scale_f32_16x16x128_f8f6f4: 2 product-equivalents per algorithmic FLOP instead of "f16x"'s 3 (include/ser_hip.h).  The packed
-# projection, FC1 and FC2 multiply in it; ser_attention and the output projection (8 % of the layer FLOPs, its A operand is the attention
-# kernel's fp16 hi + lo context rows) and the conv stem stay on fp16 hi + lo planes.  Operand error ~2^-15 (between "f16"'s 2^-11 and
+# projection, FC1, FC2 and -- with head dim 64, where ser_attention writes its context rows in the format (ABI 14) -- the output projection
+# multiply in it; ser_attention itself and the conv stem stay on fp16 hi + lo planes.  Operand error ~2^-15 (between "f16"'s 2^-11 and
 # "f16x"'s 2^-22): oracle/numerics_whatif_f16m.py, tests/test_gpu_depth.py.
 # "f16x" (round 4): the 3-product split EVERYWHERE, like "fp32x", on fp16 hi + lo planes -- 22-bit operands instead of the 16 of the
 # bf16 pair at the same cost.  The widest margin of all modes where |values| stay inside fp16's range (65 504).
@@ -301,8 +301,11 @@ class _EncoderBase:
         projection in SER_MODE_FP16M the gate rides as 2H extra output columns: the in-kernel form multiplies the layer input's operand copy,
         whose second plane is e4m3 bytes in that format."""
         if self.qkv_m_from is not None and i >= self.qkv_m_from:
-            return dict(qkv_mode=_lib.MODE_FP16M, x_mode=_lib.MODE_FP16M, qkv_out_mode=self.attn_mode, gate_in_attn=False)
-        return dict(qkv_mode=self.qkv_mode, x_mode=self.x_mode, qkv_out_mode=self.qkv_out_mode, gate_in_attn=self.gate_in_attn)
+            # ... and with head dim 64 (a head = one 64-column tile) ser_attention writes its context rows as FP16M operands, so the OUTPUT
+            # projection of these layers multiplies in the format too (what-if "qkv>=8+out>=8": 1.44e-4 / 4.1e-5; + 3 % on the default's step)
+            return dict(qkv_mode=_lib.MODE_FP16M, x_mode=_lib.MODE_FP16M, qkv_out_mode=self.attn_mode, gate_in_attn=False,
+                        out_m=self.geo.head_dim == 64 and _os.environ.get("SER_F16M_OUT_M", "1") == "1")
+        return dict(qkv_mode=self.qkv_mode, x_mode=self.x_mode, qkv_out_mode=self.qkv_out_mode, gate_in_attn=self.gate_in_attn, out_m=False)
 
     def _check_last_state(self, last_state: Optional[int]) -> Optional[int]:
         if last_state is None:
@@ -487,7 +490,7 @@ class _EncoderBase:
         check(lib.ser_row_center_v(C.byref(a), self._s()), "ser_row_center")
 
     def _attention(self, qkv: Act, frame_offs_dev, B, max_frames, out: Act, *, table=None, table_T=0, gate=None,
-                   gru_const=None, key_lens=None, bias2d=None, gate_in=None):
+                   gru_const=None, key_lens=None, bias2d=None, gate_in=None, out_m=False):
         """``gate_in`` = (operand copy of the layer input, lnstat of the packed projection, folded weights, constants): the WavLM gate
         is computed inside the kernel (ser_attention_args.gate_x) instead of read from gate columns of ``qkv``."""
         D, H, dh = self.geo.hidden, self.geo.heads, self.geo.head_dim
@@ -502,6 +505,10 @@ class _EncoderBase:
         a.max_frames, a.table_T = max_frames, table_T
         a.out, a.ldo, a.out_plane_stride = out.ptr, out.cols, out.plane_stride
         a.H, a.dh, a.scale, a.mode, a.gate_col = H, dh, -1.0, amode, gate_col       # q is pre-scaled
+        if out_m:                                                                   # context rows as SER_MODE_FP16M operands (ABI 14)
+            a.out_mode, a.out_scale, a.out_scale_ld = _lib.MODE_FP16M, out.scale.data_ptr(), out.scale_ld
+        else:
+            a.out_mode, a.out_scale, a.out_scale_ld = 0, None, 0
         a.gru_const, a.key_lens = _ptr(gru_const), _ptr(key_lens)
         a.bias2d, a.bias2d_ld = _ptr(bias2d), (0 if bias2d is None else bias2d.shape[-1])
         if gate_in is not None:
@@ -586,11 +593,11 @@ class _EncoderBase:
             self._qkv_gemm(pl, lay, M, i == 0, gx, (pl["sx"], pl["mx"]) if shifted else None)
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"],
-                                table_T=pl["Tmax"], gru_const=lay["gate_c"], gate_in=self._gate_in(pl, lay))
+                                table_T=pl["Tmax"], gru_const=lay["gate_c"], gate_in=self._gate_in(pl, lay), out_m=lay["out_m"])
             else:
-                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
+                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], out_m=lay["out_m"])
             self._gemm(pl["ctx"], lay["out"], M, residual=x, ldr=D, out_f32=pl["h"], ldo_f32=D,
-                       out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD, mode=self.attn_mode, out_mode=self.mode,
+                       out_act=pl["ha"], stat_out=pl["ph"], stat_groups=gD, mode=_lib.MODE_FP16M if lay["out_m"] else self.attn_mode, out_mode=self.mode,
                        shift=(pl["mx"], pl["sh"], lay["out_bias_mean"]) if shifted else None)
             if self.block_trace is not None:
                 b1 = torch.cuda.Event(enable_timing=True)
@@ -636,12 +643,12 @@ class _EncoderBase:
             self._qkv_gemm(pl, lay, M, i == 0, pl["first_groups"] if i == 0 else gD, (pl["sx"], pl["mx"]))
             if wavlm:
                 self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], table=pl["table"], table_T=pl["Tmax"],
-                                gru_const=lay["gate_c"], gate_in=self._gate_in(pl, lay))
+                                gru_const=lay["gate_c"], gate_in=self._gate_in(pl, lay), out_m=lay["out_m"])
             else:
-                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"])
+                self._attention(pl["qkv"], pl["frame_offs"], B, max_frames, pl["ctx"], out_m=lay["out_m"])
             self._gemm(pl["ctx"], lay["out"], M, residual=pl["h"], ldr=D, out_f32=pl["h"], ldo_f32=D, out_act=pl["ha"],
                        stat_out=pl["ph"], stat_groups=gD, shift=(pl["mx"], pl["sh"], lay["out_bias_mean"]),
-                       mode=self.attn_mode, out_mode=self.mode)
+                       mode=_lib.MODE_FP16M if lay["out_m"] else self.attn_mode, out_mode=self.mode)
         return len(self.layers)
 
     def _layer_weights(self, sd, p: str, a: str, ln1: str, ln2: str, fc1: str, fc2: str, k_bias: bool, gate: bool, index: int = 0):
@@ -652,7 +659,7 @@ class _EncoderBase:
         kb = sd[a + ".k_proj.bias"] if k_bias else torch.zeros(D, device=wdev)
         ws = [sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"], sd[a + ".v_proj.weight"]]
         bs = [sd[a + ".q_proj.bias"], kb, sd[a + ".v_proj.bias"]]
-        lay = dict(qkv_mode=lm["qkv_mode"], x_mode=lm["x_mode"], qkv_out_mode=lm["qkv_out_mode"])
+        lay = dict(qkv_mode=lm["qkv_mode"], x_mode=lm["x_mode"], qkv_out_mode=lm["qkv_out_mode"], out_m=lm["out_m"])
         if gate and lm["gate_in_attn"]:
             # WavLM GRU gate (HF modeling_wavlm.py:167-180): its two pre-activations per head are linear in LN1(x) restricted to the
             # head's dh channels.  ser_attention evaluates them per query from the layer input's operand copy with the LayerNorm in
@@ -687,7 +694,7 @@ class _EncoderBase:
             lay["qk"] = self._linear_ln(torch.cat(ws[:2] + ws[3:], 0), torch.cat(bs[:2] + bs[3:], 0), sd[ln1 + ".weight"],
                                         sd[ln1 + ".bias"], mode=self.qk_mode)
             lay["v"] = self._linear_ln(ws[2], bs[2], sd[ln1 + ".weight"], sd[ln1 + ".bias"])
-        lay["out"] = self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"], mode=self.attn_mode)
+        lay["out"] = self._linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"], mode=_lib.MODE_FP16M if lm["out_m"] else self.attn_mode)
         lay["fc1"] = self._linear_ln(sd[fc1 + ".weight"], sd[fc1 + ".bias"], sd[ln2 + ".weight"], sd[ln2 + ".bias"])
         lay["fc2"] = self._linear(sd[fc2 + ".weight"], sd[fc2 + ".bias"])
         # load-time part of the operand shift: a uniform offset in a bias moves the row mean by exactly its mean
@@ -717,7 +724,8 @@ class _EncoderBase:
         pl["px"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # FC2 outputs
         pl["ph"] = torch.zeros((M, gD, 2), dtype=torch.float32, device=dev)              # out-proj outputs
         pl["qkv"] = self._new_act(M, nqkv, mode=self._lay_modes(geo.num_layers - 1)["qkv_out_mode"])   # "f16q": q, k, gate columns carry a lo plane, v's stays unused
-        pl["ctx"] = self._new_act(M, D, mode=self.attn_mode)
+        any_out_m = any(self._lay_modes(i)["out_m"] for i in range(geo.num_layers))
+        pl["ctx"] = self._new_act(M, D, mode=_lib.MODE_FP16M if any_out_m else self.attn_mode)   # (an FP16M buffer serves the FP16X layers too)
         pl["h"] = torch.empty((M, D), dtype=torch.float32, device=dev)
         pl["ffn"] = self._new_act(M, Fd)
         pl["last"] = torch.empty((M, D), dtype=torch.float32, device=dev)

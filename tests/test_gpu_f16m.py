@@ -206,3 +206,59 @@ def test_gemm_f16m_rejects_what_it_does_not_take(L):
     Wd, Ws = device_pack(L, W, True)
     with pytest.raises(L.SerHipError):
         gemm_m(L, Ad, None, Wd, Ws, 64, 64, 64)                     # no block scales
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_attention_writes_f16m_context_rows(L, bias):
+    """ser_attention_v with out_mode = SER_MODE_FP16M (ABI 14; mode FP16X, head dim 64): plane 0 of the context rows is bit for bit the fp16 hi
+    plane of the FP16X launch, plane 1 + the scale words decode (tests/f16m_ref.py) to P = v - hi and Q = v within e4m3's half ulp of each
+    32-column block's largest element, for ragged utterances incl. one shorter than a query block, with and without the WavLM bias table."""
+    import f16m_ref as R
+    H, dh = 4, 64
+    D, Ts = H * dh, [70, 129, 5, 200]
+    M, Tmax = sum(Ts), max(Ts)
+    g = torch.Generator().manual_seed(5 + bias)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    qkv[:, 2 * D:] *= torch.logspace(-3, 2, D)[None, :]                    # value columns over five decades: the block scales matter
+    hi = qkv.to(torch.float16)
+    qa = torch.stack([hi, (qkv - hi.float()).to(torch.float16)]).contiguous().to(DEV)
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    foffs = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    table = torch.randn(H, 2 * Tmax - 1, generator=g).to(DEV) if bias else None
+    gate = (torch.rand(M, H, generator=g) * 2).to(DEV) if bias else None
+
+    def run(out_m):
+        out = torch.zeros(2, M, D, dtype=torch.float16, device=DEV)
+        sc = torch.zeros(D // 64, M, dtype=torch.int32, device=DEV)
+        a = L.AttentionArgs()
+        a.qkv, a.ld, a.plane_stride = qa.data_ptr(), 3 * D, M * 3 * D
+        a.q_col, a.k_col, a.v_col, a.B = 0, D, 2 * D, len(Ts)
+        a.frame_offs, a.max_frames = foffs.data_ptr(), Tmax
+        if bias:
+            a.table, a.table_T, a.gate = table.data_ptr(), Tmax, gate.data_ptr()
+        a.out, a.ldo, a.out_plane_stride = out.data_ptr(), D, M * D
+        a.H, a.dh, a.scale, a.mode = H, dh, -1.0, 4                        # FP16X takes a pre-scaled q
+        if out_m:
+            a.out_mode, a.out_scale, a.out_scale_ld = FP16M, sc.data_ptr(), M
+        rc = L.lib.ser_attention_v(C.byref(a), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return rc, out, sc
+
+    rc, ox, _ = run(False)
+    assert rc == 0
+    rc, om, sc = run(True)
+    assert rc == 0, L.lib.ser_last_error()
+    assert torch.equal(om[0], ox[0])                                       # the fp16 copy
+    v = ox[0].double().cpu() + ox[1].double().cpu()                        # the context rows to ~2^-22
+    x8 = om[1].contiguous().view(torch.uint8).reshape(M, 2 * D).cpu()
+    hi64, P, Q = R.decode(om[0].cpu(), x8, sc.cpu().view(torch.int32))
+    lo = v - hi64
+    bl = lambda t: t.abs().reshape(M, D // 32, 32).amax(-1, keepdim=True).expand(-1, -1, 32).reshape(M, D)   # noqa: E731
+    assert ((P - lo).abs() <= bl(lo) * 2.0 ** -3 + 1e-12).all()            # e4m3: 3 mantissa bits, power-of-two scale up to 2x the block max
+    assert ((Q - v).abs() <= bl(v) * 2.0 ** -3 + 1e-12).all()
+    assert float((Q - v).abs().max() / v.abs().max()) > 1e-4               # ... and it IS an 8-bit copy
+    # rejected: a head dim that is not one 64-column tile
+    a = L.AttentionArgs()
+    a.qkv, a.frame_offs, a.out, a.B, a.H, a.dh, a.max_frames, a.mode, a.out_mode, a.ld, a.ldo = qa.data_ptr(), foffs.data_ptr(), om.data_ptr(), 1, 4, 32, 8, 4, FP16M, 3 * D, D
+    a.scale, a.out_scale, a.out_scale_ld = -1.0, sc.data_ptr(), M
+    assert L.lib.ser_attention_v(C.byref(a), None) < 0
