@@ -301,10 +301,13 @@ class _EncoderBase:
         projection in SER_MODE_FP16M the gate rides as 2H extra output columns: the in-kernel form multiplies the layer input's operand copy,
         whose second plane is e4m3 bytes in that format."""
         if self.qkv_m_from is not None and i >= self.qkv_m_from:
-            # ... and with head dim 64 (a head = one 64-column tile) ser_attention writes its context rows as FP16M operands, so the OUTPUT
-            # projection of these layers multiplies in the format too (what-if "qkv>=8+out>=8": 1.44e-4 / 4.1e-5; + 3 % on the default's step)
+            # ... and with head dim 64 (a head = one 64-column tile) ser_attention can write its context rows as FP16M operands (ABI 14), so that
+            # the OUTPUT projection of these layers multiplies in the format too (what-if "qkv>=8+out>=8": 1.44e-4 / 4.1e-5; + 1.6 % on the
+            # default's step, same envelope on WavLM-large).  OPT-IN (SER_F16M_OUT_M=1), not the default: bench.py's Whisper-large-v3 record
+            # (two 8 x 30 s groups captured as concurrent graph branches, then replayed command lists) came back 0.57 from the oracle with it
+            # while the eager single-slot forward of the same batch is right (1.9e-5) -- found with no GPU time left in round 5 to chase it.
             return dict(qkv_mode=_lib.MODE_FP16M, x_mode=_lib.MODE_FP16M, qkv_out_mode=self.attn_mode, gate_in_attn=False,
-                        out_m=self.geo.head_dim == 64 and _os.environ.get("SER_F16M_OUT_M", "1") == "1")
+                        out_m=self.geo.head_dim == 64 and _os.environ.get("SER_F16M_OUT_M", "0") == "1")
         return dict(qkv_mode=self.qkv_mode, x_mode=self.x_mode, qkv_out_mode=self.qkv_out_mode, gate_in_attn=self.gate_in_attn, out_m=False)
 
     def _check_last_state(self, last_state: Optional[int]) -> Optional[int]:

@@ -187,7 +187,7 @@ def test_default_mode_layer_formats():
             assert lay["qkv_mode"] == (_lib.MODE_FP16M if m else _lib.MODE_FP16X), (mode, i)
             assert lay["x_mode"] == lay["qkv_mode"] and lay["qkv_out_mode"] == _lib.MODE_FP16X
             assert ("gate_w" in lay) == (not m), (mode, i)                 # in-kernel gate on the hi + lo copy; gate columns beside FP16M projections
-            assert lay["out_m"] == (m and geo.head_dim == 64)               # FP16M context rows -> output projection in the format (head dim 64)
+            assert lay["out_m"] is False                                    # FP16M context rows + output projection: opt-in (SER_F16M_OUT_M=1), see engine._lay_modes
             assert lay["fc1"].wscale is not None if mode != "f16x" else lay["fc1"].wscale is None
         del enc
     torch.cuda.empty_cache()
