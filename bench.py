@@ -759,8 +759,8 @@ def main():
                             "~2^-15); conv stem, attention and output projection on the fp16 hi + lo split (full-depth stress cases: "
                             "profiles/r05_depth_envelope_f16m*.txt, <= 4.8e-4, inside fp32x's on every case)",
                     "f16mf": "round 5, the drivers' default: f16x with the feed-forward pair (FC1, FC2: 2/3 of the layer FLOPs) of every layer and "
-                             "the packed projection and (head dim 64) the output projection from a third of the depth on in f16m's operand format; conv "
-                             "stem, attention and the first third's projections on the fp16 hi + lo split (full-depth stress "
+                             "the packed projection from a third of the depth on in f16m's operand format; conv stem, attention, output "
+                             "projection and the first third's packed projections on the fp16 hi + lo split (full-depth stress "
                              "cases, all four encoder families: profiles/r05_depth_envelope_f16mf.txt, <= 2.2e-4, 2-7x inside fp32x's on every case)",
                     "f16": "fp32x conv stem (conv stack, projection, positional conv) + fp16 single-product encoder layers",
                     "f16a": "fp32x conv stem; packed QKV projection, attention (S = K Q^T, P V) and output projection on the 3-product "

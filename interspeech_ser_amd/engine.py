@@ -32,15 +32,15 @@ from .config import EncoderGeometry, FAMILY_ROBERTA, FAMILY_WAVLM, FAMILY_WHISPE
 MODES = {"bf16": _lib.MODE_BF16, "fp32x": _lib.MODE_FP32X, "f16": _lib.MODE_FP16, "f16q": _lib.MODE_FP16, "f16a": _lib.MODE_FP16,
          "f16x": _lib.MODE_FP16X, "f16m": _lib.MODE_FP16M, "f16mf": _lib.MODE_FP16M}
 # "f16mf" (round 5, the drivers' default): "f16m" where it is benign -- FC1 and FC2 (2/3 of the layer FLOPs) in every layer, the packed
-# projection and (head dim 64) the output projection from a third of the depth on (_EncoderBase.qkv_m_from, _lay_modes); the conv stem,
-# ser_attention and the first third's projections keep "f16x"'s three products on fp16 hi + lo planes.  oracle/numerics_whatif_f16m.py (site lists): under sharp
+# projection from a third of the depth on (_EncoderBase.qkv_m_from, _lay_modes); the conv stem, ser_attention, the output projection and
+# the first third's packed projections keep "f16x"'s three products on fp16 hi + lo planes.  oracle/numerics_whatif_f16m.py (site lists): under sharp
 # attention the error of "f16m" comes from the packed projections of the FIRST layers (an error injected by layer i passes through L - i
 # more softmax layers): all of them 4.3e-4 of f16m's 5.2e-4 at 24 layers, from layer 8 on nothing measurable; FC1 + FC2 alone give 1.4e-4
 # (sharp x2), 2.7e-5 (LoRA), 1.3e-5 (plain) -- inside "fp32x"'s on each.  The stem in that format: 1.4e-3 (it stays on 22 bits).
 # "f16m" (round 5): the encoder layers' GEMMs on SER_MODE_FP16M operands -- fp16 main product + block-scaled e4m3 cross terms on gfx950's
 # v_mfma_scale_f32_16x16x128_f8f6f4: 2 product-equivalents per algorithmic FLOP instead of "f16x"'s 3 (include/ser_hip.h).  The packed
-# projection, FC1, FC2 and -- with head dim 64, where ser_attention writes its context rows in the format (ABI 14) -- the output projection
-# multiply in it; ser_attention itself and the conv stem stay on fp16 hi + lo planes.  Operand error ~2^-15 (between "f16"'s 2^-11 and
+# projection, FC1 and FC2 multiply in it (opt-in, SER_F16M_OUT_M=1, head dim 64: the output projection too, on FP16M context rows out of
+# ser_attention, ABI 14); ser_attention, the output projection and the conv stem stay on fp16 hi + lo planes.  Operand error ~2^-15 (between "f16"'s 2^-11 and
 # "f16x"'s 2^-22): oracle/numerics_whatif_f16m.py, tests/test_gpu_depth.py.
 # "f16x" (round 4): the 3-product split EVERYWHERE, like "fp32x", on fp16 hi + lo planes -- 22-bit operands instead of the 16 of the
 # bf16 pair at the same cost.  The widest margin of all modes where |values| stay inside fp16's range (65 504).
